@@ -1,0 +1,256 @@
+/*
+ * ptgpu.h — C ABI of libptgpu, the MI355X (gfx950) implementation of the
+ * PathTracer rendering hot path.
+ *
+ * The seam is the reference's `Renderer` class at frame granularity
+ * (reference src/renderer.h:37-71).  The per-ray virtual interfaces
+ * `IAccelerationStructure::intersect_ray` (src/acceleration_structure.h:63-69)
+ * and `IRayProgram::on_hit` (src/ray_program.h:58-63) are selected by enums in
+ * `Renderer::load_scene` (src/renderer.cc:44-63); here they become device
+ * kernels chosen by the same enums in `ptgpu_settings`.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes, no C++ or torch types;
+ *   - every call returns 0 on success or a negative PTGPU_E_* code; the text
+ *     of the last failure of a context is `ptgpu_last_error(ctx)`;
+ *   - matrices are column-major float[16] (m[col*4+row]), as glm stores them;
+ *   - host pointers are copied during the call (the caller may free them
+ *     afterwards); pointers whose name starts with `d_` are device pointers;
+ *   - one context per GPU per process, driven from one host thread.
+ *   - the library never falls back to the CPU: without a usable gfx950
+ *     device `ptgpu_create` fails.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes ------------------------------------------------------- */
+#define PTGPU_OK 0
+#define PTGPU_E_INVALID (-1)   /* bad argument / inconsistent model          */
+#define PTGPU_E_NODEVICE (-2)  /* no usable HIP device                       */
+#define PTGPU_E_HIP (-3)       /* a HIP runtime call failed                  */
+#define PTGPU_E_STATE (-4)     /* call order: scene or camera not set        */
+#define PTGPU_E_NOMEM (-5)     /* allocation failed / ray pool too small     */
+
+/* ---- enums (reference src/arguments.h:10-23) --------------------------- */
+enum { PTGPU_PROGRAM_RAYCASTER = 0, PTGPU_PROGRAM_AO = 1, PTGPU_PROGRAM_PBR = 2 };
+enum { PTGPU_AS_NAIVE = 0, PTGPU_AS_BVH = 1 };
+
+/* ---- scene data contract (reference src/model_loader.h:14-65) ---------- */
+
+/* `vertex` (model_loader.h:14-19): 12 floats, 48 bytes. */
+typedef struct ptgpu_vertex {
+    float position[3];
+    float normal[3];
+    float tangent[4]; /* xyz + handedness sign in w */
+    float uv[2];
+} ptgpu_vertex;
+
+/* `Mesh` (model_loader.h:21-25): a glTF primitive.  Indices are relative to
+ * the mesh's own vertex range and n_indices is a multiple of 3. */
+typedef struct ptgpu_mesh {
+    uint32_t first_vertex; /* into ptgpu_model.vertices */
+    uint32_t n_vertices;
+    uint32_t first_index; /* into ptgpu_model.indices  */
+    uint32_t n_indices;
+    uint32_t material_index;
+} ptgpu_mesh;
+
+/* `Object` (model_loader.h:27-31): NormalMatrix = transpose(inverse(Model)). */
+typedef struct ptgpu_object {
+    float model_matrix[16];
+    float normal_matrix[16];
+    uint32_t mesh_index;
+} ptgpu_object;
+
+/* `Material` (model_loader.h:33-52); texture indices are image indices, -1 = none. */
+typedef struct ptgpu_material {
+    float base_color_factor[4];
+    float emissive_factor[3];
+    float attenuation_factor[3];
+    float metallic_factor;
+    float roughness_factor;
+    int32_t base_color_texture;
+    int32_t metallic_roughness_texture;
+    int32_t normal_texture;
+    float ior;
+    float dielectric_f0;
+    float transmission_factor;
+    int32_t transmission_texture;
+    int32_t emissive_texture;
+    float emissive_strength;
+    int32_t double_sided;
+    int32_t has_volume;
+    int32_t alpha_blending;
+    float alpha_cutoff;
+} ptgpu_material;
+
+/* `CPUTexture<sdr_pixel>` (cpu_framebuffer.h:61-133): RGBA8 rows, top row first. */
+typedef struct ptgpu_image {
+    int32_t width;
+    int32_t height;
+    uint64_t texel_offset; /* in pixels, into ptgpu_model.texels (4 bytes per pixel) */
+} ptgpu_image;
+
+/* `Model` (model_loader.h:59-65) as flat arrays. */
+typedef struct ptgpu_model {
+    const ptgpu_vertex* vertices;
+    uint64_t n_vertices;
+    const uint32_t* indices;
+    uint64_t n_indices;
+    const ptgpu_mesh* meshes;
+    uint32_t n_meshes;
+    const ptgpu_object* objects;
+    uint32_t n_objects;
+    const ptgpu_material* materials;
+    uint32_t n_materials;
+    const ptgpu_image* images;
+    uint32_t n_images;
+    const uint8_t* texels;
+    uint64_t n_texels; /* pixels */
+} ptgpu_model;
+
+/* `CPUTexture<hdr_pixel>` environment map: RGBA32F rows, top row first. */
+typedef struct ptgpu_envmap {
+    int32_t width;
+    int32_t height;
+    const float* rgba;
+} ptgpu_envmap;
+
+/* `RenderSettings` (reference src/render_settings.h:7-21) plus what the GPU
+ * path adds: the seed of the counter-based sampler (the reference seeds a
+ * thread-local minstd_rand from std::random_device, ray_program.cc:169,231)
+ * and the sample subset rendered by this context (multi-GPU sample split). */
+typedef struct ptgpu_settings {
+    uint32_t samples_per_pixel;
+    uint32_t max_ray_bounces; /* used modulo 256 like the uint8 cast at renderer.cc:73 */
+    uint32_t max_new_rays_per_bounce;
+    uint32_t max_triangles_per_bvh_leaf;
+    float envmap_rotation; /* radians */
+    int32_t program_mode;  /* PTGPU_PROGRAM_* */
+    int32_t accel_struct_type; /* PTGPU_AS_* */
+    uint32_t seed;
+    uint32_t sample_begin; /* first global sample index rendered here (default 0) */
+    uint32_t sample_step;  /* stride between rendered sample indices (default 1; 0 means 1) */
+} ptgpu_settings;
+
+/* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
+ * src/ray_program.h:29-56 (raycast parity dump). */
+typedef struct ptgpu_hit {
+    float t; /* +inf on miss */
+    float A;
+    float B;
+    uint32_t object_index;
+    uint32_t mesh_index;
+    uint32_t triangle_index; /* index of the triangle's first entry in mesh indices */
+    uint32_t hit;            /* 1 = forward hit (hit && t > 0) */
+    uint32_t backface;
+} ptgpu_hit;
+
+/* Counters and timings of the last ptgpu_render_* call. */
+typedef struct ptgpu_stats {
+    uint64_t rays;           /* intersect_ray calls: camera + secondary + pass-through */
+    uint64_t camera_samples; /* (pixel, sample) pairs generated */
+    uint64_t extend_launches;
+    uint64_t shade_launches;
+    double extend_ms;  /* sum of HIP-event durations of the extend kernel launches */
+    double shade_ms;   /* same for the shade kernels */
+    double generate_ms;
+    double total_ms;   /* HIP-event time from first to last kernel of the call */
+    uint64_t nodes_visited;    /* filled only by ptgpu_render_counted */
+    uint64_t triangles_tested; /* idem */
+    uint64_t instances_tested; /* idem */
+    uint64_t instances_entered; /* idem */
+} ptgpu_stats;
+
+typedef struct ptgpu_bvh_info {
+    uint32_t n_nodes;  /* inner nodes of the flattened tree */
+    uint32_t n_leaves;
+    uint32_t n_triangles;
+    uint32_t min_depth, max_depth;
+    float mean_depth;
+    uint32_t min_tris_in_leaf, max_tris_in_leaf;
+    float mean_tris_in_leaf;
+    uint64_t checksum; /* FNV-1a over leaf order of triangle indices and leaf sizes */
+} ptgpu_bvh_info;
+
+typedef struct ptgpu_ctx ptgpu_ctx;
+
+/* Create a context on HIP device `device_id`.  Fails with PTGPU_E_NODEVICE if
+ * there is no such device or it is not a gfx950 part. */
+int ptgpu_create(int device_id, ptgpu_ctx** out);
+void ptgpu_destroy(ptgpu_ctx* ctx);
+const char* ptgpu_last_error(const ptgpu_ctx* ctx); /* ctx may be NULL: last create error */
+
+/* Renderer::set_render_settings (src/renderer.cc:125). Takes effect on the
+ * next ptgpu_load_scene for AS/program choices, like the reference, and
+ * immediately for spp / bounces / seed / sample subset. */
+int ptgpu_set_render_settings(ptgpu_ctx* ctx, const ptgpu_settings* settings);
+int ptgpu_get_render_settings(const ptgpu_ctx* ctx, ptgpu_settings* out);
+
+/* Renderer::load_scene (src/renderer.cc:41-64): builds the two-level
+ * acceleration structure on the host exactly like BVH_AS::BVH_AS
+ * (src/acceleration_structure.cc:352-536), flattens it to the device layout
+ * and uploads geometry, materials, textures and the environment map. */
+int ptgpu_load_scene(ptgpu_ctx* ctx, const ptgpu_model* model, const ptgpu_envmap* env);
+
+/* Renderer::update_camera_transform_state (src/renderer.cc:27-39).
+ * aspect <= 0 selects the reference default 1.7777778, zfar <= 0 selects 1000. */
+int ptgpu_update_camera_transform_state(ptgpu_ctx* ctx, const float position[3], const float direction[3],
+                                        const float up[3], float yfov, float aspect, float znear, float zfar);
+/* Same state set directly: NDC2World matrix and ray origin. */
+int ptgpu_set_camera_raw(ptgpu_ctx* ctx, const float ndc2world[16], const float origin[3]);
+int ptgpu_get_camera_raw(const ptgpu_ctx* ctx, float ndc2world[16], float origin[3]);
+
+/* Renderer::get_scene_bound (src/renderer.cc:128-133). */
+int ptgpu_get_scene_bound(const ptgpu_ctx* ctx, float bmin[3], float bmax[3]);
+
+/* Renderer::render_frame (src/renderer.cc:77-123): renders width x height
+ * pixels with the current settings and writes the mean colour, alpha = 1, as
+ * width*height RGBA float rows (top row first) to host memory. */
+int ptgpu_render_frame(ptgpu_ctx* ctx, int width, int height, float* out_rgba, ptgpu_stats* stats);
+
+/* Device-resident variant for multi-GPU sample split: leaves the SUM over this
+ * context's sample subset in `d_sum_rgba` (width*height*4 floats on the
+ * context's device, alpha channel = number of samples summed) without dividing.
+ * `stream` is a hipStream_t (NULL = the context's own stream); the call returns
+ * after the work has completed on that stream. */
+int ptgpu_render_frame_sums(ptgpu_ctx* ctx, int width, int height, float* d_sum_rgba, void* stream,
+                            ptgpu_stats* stats);
+
+/* Divide a summed RGBA buffer by its sample count and set alpha = 1
+ * (the `get_mean()` of src/renderer.h:31 applied to all pixels), on device. */
+int ptgpu_resolve_sums(ptgpu_ctx* ctx, int width, int height, float* d_sum_rgba, uint32_t total_samples,
+                       void* stream);
+
+/* Same frame as ptgpu_render_frame, traced by the counting variant of the
+ * extend kernel: fills nodes_visited / triangles_tested / instances_* in stats. */
+int ptgpu_render_counted(ptgpu_ctx* ctx, int width, int height, float* out_rgba, ptgpu_stats* stats);
+
+/* Primary-ray hit records for sample index `sample` of every pixel
+ * (what BVH_AS::intersect_ray returns for the camera rays, src/renderer.cc:110-115). */
+int ptgpu_render_hits(ptgpu_ctx* ctx, int width, int height, uint32_t sample, ptgpu_hit* out);
+
+/* General-purpose intersect_ray batch (IAccelerationStructure::intersect_ray,
+ * src/acceleration_structure.h:66): n rays, origins/directions as xyz triples,
+ * any_hit[i] != 0 selects any-hit traversal (NULL = closest hit). */
+int ptgpu_intersect_rays(ptgpu_ctx* ctx, uint64_t n, const float* origins, const float* directions,
+                         const uint8_t* any_hit, ptgpu_hit* out);
+
+/* Tree statistics of one mesh BVH (MeshBVHData::collect_tree_info,
+ * src/acceleration_structure.cc:538-570). */
+int ptgpu_get_bvh_info(const ptgpu_ctx* ctx, uint32_t mesh_index, ptgpu_bvh_info* out);
+
+/* Sub-pixel sample table (Renderer::generate_subsample_positions,
+ * src/renderer.cc:135-155): writes spp (x, y) pairs. Host-only helper. */
+int ptgpu_subsample_positions(uint32_t spp, float* out_xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */
