@@ -1,0 +1,64 @@
+// pt_kernels.h — host-callable launchers of the wavefront kernels (generate, extend, shade, resolve).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_device.h"
+
+namespace ptd {
+
+constexpr int kBlock = 256;          // threads per workgroup: 4 wavefronts of 64 lanes
+constexpr int kStackLds = 16;        // per-lane traversal stack entries kept in LDS; deeper entries spill to HBM
+constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
+constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
+
+// Structure-of-arrays ray records, 48 B per ray:
+//   o = origin.xyz, framebuffer slot (uint)        d = direction.xyz, depth | any_hit << 8 (uint)
+//   p = payload.rgb, sampler key (uint)
+struct RayQueue {
+    float4* o;
+    float4* d;
+    float4* p;
+};
+// Hit records, 20 B per ray: h0 = t, A, B, triangle index (uint); h1 = object | backface << 30 | hit << 31
+struct HitQueue {
+    float4* h0;
+    uint32_t* h1;
+};
+
+struct CameraDev {
+    float ndc2world[16];  // column-major
+    float origin[3];
+    float inv_w, inv_h;
+    int32_t width, height;
+    int32_t tiles_x, tiles_y;
+};
+
+struct FrameDev {
+    float* sum;          // planar R | G | B sums, each `stride` floats, indexed by framebuffer slot
+    uint32_t stride;
+};
+
+struct TraceCounters {   // filled by the counting variant of extend
+    unsigned long long nodes, tris, inst_tested, inst_entered;
+};
+
+// camera samples [first, first + n): index = (sample_slot * n_tiles + tile) * 64 + lane
+void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
+                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n, RayQueue out,
+                     uint32_t* out_count);
+void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
+                   uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters);
+// program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
+void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples);
+void launch_clear(hipStream_t st, float* p, uint64_t n);
+// planar tiled sums -> row-major RGBA: rgb = sum / divisor (samples for the mean, 1 for raw sums), a = alpha
+void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha);
+// row-major RGBA sums -> means in place: rgb /= divisor, a = 1
+void launch_divide_rgba(hipStream_t st, float* rgba, uint64_t n_pixels, float divisor);
+void launch_pack_rays(hipStream_t st, const float* origins, const float* directions, const uint8_t* any_hit, uint32_t n,
+                      RayQueue out);
+
+}  // namespace ptd

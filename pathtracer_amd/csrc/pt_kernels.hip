@@ -1,0 +1,870 @@
+// pt_kernels.hip — wavefront path-tracing kernels for gfx950 (MI355X).
+//
+//   generate  camera rays for a range of (sample, 8x8 tile, lane) indices          renderer.cc:17-21, 66-75
+//   extend    two-level traversal: instance DOPs, per-mesh binary BVH, triangles   acceleration_structure.cc:587-708
+//   shade     RayCaster / AmbientOcclusion / PBR programs; spawned rays are          ray_program.cc:150-391
+//             compacted per wavefront with ballots and appended with one atomic
+//   resolve   tiled planar sums -> row-major RGBA means                             renderer.cc:118-120
+//
+// (citations: files of the reference renderer whose arithmetic each kernel reproduces)
+//
+// One lane owns one ray.  Traversal stacks are per lane: the first kStackLds entries of every lane
+// live in LDS as stack[entry][lane] (bank = lane % 32 for every entry, so pushes and pops never
+// conflict whatever the lanes' stack heights); deeper entries go to a per-lane HBM spill area.
+#include "pt_kernels.h"
+
+#include <algorithm>
+
+namespace ptd {
+
+namespace {
+
+constexpr float kInfF = __builtin_inff();
+constexpr float kPiF = 3.14159265358979323846264338327950288f;
+constexpr float kInvSqrt3 = 0.577350269189625764509148780501957456f;
+
+__device__ __forceinline__ f3 ld3(const float4& v) { return f3{v.x, v.y, v.z}; }
+
+// ---------------------------------------------------------------------------------------------
+// volumes
+// ---------------------------------------------------------------------------------------------
+// ray_volume_hit_info::forward_hit_distance (ray_program.h:44-47)
+__device__ __forceinline__ float forward_distance(bool hit, float t0, float t1) {
+    return (hit && (t1 > 0.0f)) ? (t0 > 0.0f ? t0 : 0.0f) : kInfF;
+}
+// BBox::ray_volume_intersection(ray, inv_dir) (acceleration_structure.cc:109-122)
+__device__ __forceinline__ void box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv,
+                                         bool& hit, float& dist) {
+    float ax = (lox - o.x) * inv.x, ay = (loy - o.y) * inv.y, az = (loz - o.z) * inv.z;
+    float bx = (hix - o.x) * inv.x, by = (hiy - o.y) * inv.y, bz = (hiz - o.z) * inv.z;
+    float t0x = sel_min(ax, bx), t0y = sel_min(ay, by), t0z = sel_min(az, bz);
+    float t1x = sel_max(ax, bx), t1y = sel_max(ay, by), t1z = sel_max(az, bz);
+    t0x = (t0x > t0y) ? t0x : t0y;
+    t0x = (t0x > t0z) ? t0x : t0z;
+    t1x = (t1x < t1y) ? t1x : t1y;
+    t1x = (t1x < t1z) ? t1x : t1z;
+    hit = (t0x <= t1x);
+    dist = forward_distance(hit, t0x, t1x);
+}
+// DOP::ray_volume_intersection with the ray projections formed in place
+// (acceleration_structure.cc:192-206, 593-597; axes acceleration_structure.h:50-58)
+__device__ __forceinline__ float dop_forward_distance(const float* __restrict__ dop, f3 o, f3 d) {
+    const f3 axes[7] = {f3{1.0f, 0.0f, 0.0f}, f3{0.0f, 1.0f, 0.0f}, f3{0.0f, 0.0f, 1.0f},
+                        f3{kInvSqrt3, kInvSqrt3, kInvSqrt3}, f3{kInvSqrt3, kInvSqrt3, -kInvSqrt3},
+                        f3{kInvSqrt3, -kInvSqrt3, kInvSqrt3}, f3{-kInvSqrt3, kInvSqrt3, kInvSqrt3}};
+    float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
+    bool hit = true;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        float op = dot3(o, axes[i]);
+        float ip = 1.0f / dot3(d, axes[i]);
+        float t0 = (dop[2 * i] - op) * ip;
+        float t1 = (dop[2 * i + 1] - op) * ip;
+        if (t0 > t1) { float s = t0; t0 = t1; t1 = s; }
+        tmin = (tmin < t0) ? t0 : tmin;  // std::max(t0, tmin)
+        tmax = (t1 < tmax) ? t1 : tmax;  // std::min(t1, tmax)
+        if (hit && (tmax < tmin)) hit = false;  // the reference returns here; later axes cannot un-miss
+    }
+    return forward_distance(hit, tmin, tmax);
+}
+
+struct LaneHit {
+    float t, A, B;
+    uint32_t tri, object;
+    bool hit, backface;
+};
+
+struct TraceCount {
+    uint32_t nodes, tris, inst_tested, inst_entered;
+};
+
+// Moller-Trumbore exactly as acceleration_structure.cc:16-49; returns true when the triangle is hit
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 p1, f3 p2, f3 p3, bool cull, float& A, float& B, float& t,
+                                             bool& backface) {
+    f3 e1 = p2 - p1, e2 = p3 - p1;
+    f3 pv = cross3(d, e2);
+    float det = dot3(e1, pv);
+    if (det == 0.0f) return false;
+    if (cull && det < 0.0f) return false;
+    float inv_det = 1.0f / det;
+    f3 tv = o - p1;
+    float u = dot3(tv, pv) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qv = cross3(tv, e1);
+    float v = dot3(d, qv) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot3(e2, qv) * inv_det;
+    A = 1.0f - u - v;
+    B = u;
+    backface = (det < 0.0f) && !cull;
+    return true;
+}
+
+// BVH_AS::mesh_ray_intersection (acceleration_structure.cc:635-708) for one instance.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot, f3 o_ws, f3 d_ws, LaneHit& best,
+                                               uint32_t (*stack)[kBlock], uint32_t* __restrict__ spill,
+                                               uint32_t spill_depth, uint32_t spill_stride, uint32_t gid, TraceCount& cnt) {
+    const DevXform& xf = sc.xforms[slot];
+    const f3 o = xform(xf.inv, o_ws, 1.0f);
+    const f3 d = normalize3(xform(xf.inv, d_ws, 0.0f));
+    const f3 inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+    const bool cull = xf.cull != 0;
+    const uint32_t tid = threadIdx.x;
+
+    float h_t = kInfF, h_A = 0.0f, h_B = 0.0f;
+    uint32_t h_tri = 0;
+    bool h_hit = false, h_back = false;
+
+    int sp = 0;
+    uint32_t cur = xf.root;
+    for (;;) {
+        if (cur & PT_LEAF_BIT) {
+            const uint32_t first = cur & ~PT_LEAF_BIT;
+            const float4* tp = reinterpret_cast<const float4*>(sc.tris + first);
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            const uint32_t count = __float_as_uint(q2.z);
+            for (uint32_t k = 0;;) {
+                if (COUNT) ++cnt.tris;
+                float A, B, t;
+                bool bf;
+                bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x}, cull, A, B,
+                                       t, bf);
+                if (ok && !(t < 0.0f) && !(t >= h_t)) {
+                    h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                    h_tri = __float_as_uint(q2.y);
+                    if (ANY) break;
+                }
+                if (++k >= count) break;
+                tp += 3;
+                q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
+            }
+            if (ANY && h_hit) break;
+            if (sp == 0) break;
+            --sp;
+            cur = (sp < kStackLds) ? stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid];
+        } else {
+            if (COUNT) ++cnt.nodes;
+            const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            bool hl, hr;
+            float dl, dr;
+            box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, hl, dl);
+            box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, hr, dr);
+            const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+            const bool take_l = hl && (h_t > dl), take_r = hr && (h_t > dr);
+            // the reference pushes the farther child first and pops the nearer one next; the nearer
+            // child is kept in a register here instead of a push followed by a pop
+            const bool l_first = dl < dr;
+            const uint32_t near_ref = l_first ? left : right, far_ref = l_first ? right : left;
+            const bool take_near = l_first ? take_l : take_r, take_far = l_first ? take_r : take_l;
+            if (take_near) {
+                if (take_far) {
+                    if (sp < kStackLds) stack[sp][tid] = far_ref;
+                    else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
+                        spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid] = far_ref;
+                    ++sp;
+                }
+                cur = near_ref;
+            } else if (take_far) {
+                cur = far_ref;
+            } else {
+                if (sp == 0) break;
+                --sp;
+                cur = (sp < kStackLds) ? stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid];
+            }
+        }
+    }
+    if (!h_hit) return;
+    // back to a world-space distance (acceleration_structure.cc:704-706)
+    const f3 p = o + d * h_t;
+    const f3 p_ws = xform(xf.model, p, 1.0f);
+    const float t_ws = length3(p_ws - o_ws);
+    // acceptance at the top level (acceleration_structure.cc:616-623)
+    if ((t_ws > 0.0f) && (t_ws < best.t)) {
+        best.t = t_ws; best.A = h_A; best.B = h_B; best.tri = h_tri; best.hit = true; best.backface = h_back;
+        best.object = xf.object_index;
+    }
+}
+
+// BVH_AS::intersect_ray (acceleration_structure.cc:587-633)
+template <bool COUNT>
+__device__ __forceinline__ LaneHit intersect_ray(const SceneDev& sc, f3 o, f3 d, bool any_hit, uint32_t (*stack)[kBlock],
+                                                 float (*dist_cache)[kBlock], uint32_t* spill, uint32_t spill_depth,
+                                                 uint32_t spill_stride, uint32_t gid, TraceCount& cnt) {
+    LaneHit best;
+    best.t = kInfF; best.A = 0.0f; best.B = 0.0f; best.tri = 0; best.object = 0; best.hit = false; best.backface = false;
+    const uint32_t n_inst = sc.n_instances;
+    const uint32_t tid = threadIdx.x;
+    if (any_hit) {
+        // cheapest objects first: walk the complexity-sorted table from the back, stop at the first hit
+        for (uint32_t k = n_inst; k-- > 0;) {
+            if (COUNT) ++cnt.inst_tested;
+            float dist = dop_forward_distance(sc.instances[k].dop, o, d);
+            if (dist < kInfF) {
+                if (COUNT) ++cnt.inst_entered;
+                trace_instance<true, COUNT>(sc, k, o, d, best, stack, spill, spill_depth, spill_stride, gid, cnt);
+                if (best.hit) break;
+            }
+        }
+        return best;
+    }
+    // closest hit: visit instances in order of increasing DOP entry distance (ties: table order),
+    // stop when the nearest unvisited entry is not in front of the current hit
+    for (uint32_t k = 0; k < n_inst; ++k) {
+        if (COUNT) ++cnt.inst_tested;
+        float dist = dop_forward_distance(sc.instances[k].dop, o, d);
+        if (k < kInstLds) dist_cache[k][tid] = dist;
+    }
+    float last_d = -1.0f;
+    uint32_t last_k = 0;
+    for (;;) {
+        float best_d = kInfF;
+        uint32_t best_k = PT_NO_NODE;
+        for (uint32_t k = 0; k < n_inst; ++k) {
+            float dist = (k < kInstLds) ? dist_cache[k][tid] : dop_forward_distance(sc.instances[k].dop, o, d);
+            bool after = (dist > last_d) || (dist == last_d && k > last_k);
+            if (after && dist < best_d) { best_d = dist; best_k = k; }
+        }
+        if (best_k == PT_NO_NODE || !(best_d < best.t)) break;
+        if (COUNT) ++cnt.inst_entered;
+        trace_instance<false, COUNT>(sc, best_k, o, d, best, stack, spill, spill_depth, spill_stride, gid, cnt);
+        last_d = best_d;
+        last_k = best_k;
+    }
+    return best;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                        const float4* __restrict__ ray_d, uint32_t n,
+                                                        float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                                        uint32_t* __restrict__ spill, uint32_t spill_depth,
+                                                        uint32_t spill_stride, TraceCounters* counters) {
+    __shared__ uint32_t s_stack[kStackLds][kBlock];
+    __shared__ float s_dist[kInstLds][kBlock];
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    TraceCount cnt{0, 0, 0, 0};
+    if (gid < n) {
+        const float4 ro = ray_o[gid], rd = ray_d[gid];
+        const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
+        LaneHit h = intersect_ray<COUNT>(sc, ld3(ro), ld3(rd), any_hit, s_stack, s_dist, spill, spill_depth, spill_stride,
+                                         gid, cnt);
+        hit0[gid] = make_float4(h.t, h.A, h.B, __uint_as_float(h.tri));
+        hit1[gid] = h.object | (h.backface ? 0x40000000u : 0u) | (h.hit ? 0x80000000u : 0u);
+    }
+    if (COUNT) {
+        atomicAdd(&counters->nodes, static_cast<unsigned long long>(cnt.nodes));
+        atomicAdd(&counters->tris, static_cast<unsigned long long>(cnt.tris));
+        atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(cnt.inst_tested));
+        atomicAdd(&counters->inst_entered, static_cast<unsigned long long>(cnt.inst_entered));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generate
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const float2* __restrict__ sub,
+                                                          uint32_t sample_begin, uint32_t sample_step,
+                                                          uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
+                                                          RayQueue out, uint32_t* __restrict__ out_count) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool valid = false;
+    float4 o4, d4, p4;
+    if (i < n) {
+        const uint64_t g = first + i;
+        const uint32_t n_tiles = static_cast<uint32_t>(cam.tiles_x) * cam.tiles_y;
+        const uint32_t lane = static_cast<uint32_t>(g & 63u);
+        const uint64_t tile_lin = g >> 6;
+        const uint32_t tile = static_cast<uint32_t>(tile_lin % n_tiles);
+        const uint32_t slot = static_cast<uint32_t>(tile_lin / n_tiles);
+        const uint32_t sample = sample_begin + slot * sample_step;
+        const int x = static_cast<int>((tile % cam.tiles_x) * kTile + (lane & 7u));
+        const int y = static_cast<int>((tile / cam.tiles_x) * kTile + (lane >> 3));
+        if (x < cam.width && y < cam.height) {
+            valid = true;
+            const float2 s = sub[sample];
+            // ndc_from_pixel + generate_camera_ray (renderer.cc:17-21, 66-75)
+            const float px = static_cast<float>(x) + s.x, py = static_cast<float>(y) + s.y;
+            const float nx = px * cam.inv_w * 2.0f - 1.0f;
+            const float ny = -py * cam.inv_h * 2.0f + 1.0f;
+            const float* m = cam.ndc2world;
+            f3 dir;  // xyz of mat4 * (nx, ny, 0, 1): (c0*x + c1*y) + (c2*z + c3*w)
+            dir.x = (m[0] * nx + m[4] * ny) + (m[8] * 0.0f + m[12] * 1.0f);
+            dir.y = (m[1] * nx + m[5] * ny) + (m[9] * 0.0f + m[13] * 1.0f);
+            dir.z = (m[2] * nx + m[6] * ny) + (m[10] * 0.0f + m[14] * 1.0f);
+            dir = normalize3(dir);
+            const uint32_t pid = tile * 64u + lane;
+            const uint32_t pixel = static_cast<uint32_t>(y) * cam.width + x;
+            o4 = make_float4(cam.origin[0], cam.origin[1], cam.origin[2], __uint_as_float(pid));
+            d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float(max_bounces & 0xffu));
+            p4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_camera_key(seed, pixel, sample)));
+        }
+    }
+    // wavefront compaction: one atomic per wave, rays of a wave stay contiguous and ordered
+    const unsigned long long mask = __ballot(valid);
+    const uint32_t lane_id = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane_id == 0 && mask) base = atomicAdd(out_count, static_cast<uint32_t>(__popcll(mask)));
+    base = __shfl(base, 0);
+    if (valid) {
+        const uint32_t dst = base + __popcll(mask & ((1ull << lane_id) - 1ull));
+        out.o[dst] = o4;
+        out.d[dst] = d4;
+        out.p[dst] = p4;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// textures and materials (cpu_framebuffer.h:35-50, 90-123; brdf.cc:11-69)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap_coord(int v, int n) {  // ((v % n) + n) % n
+    int r = v % n;
+    return (r < 0) ? r + n : r;
+}
+struct Taps {
+    int x0, y0, x1, y1;
+    float tx, ty;
+};
+__device__ __forceinline__ Taps bilinear_taps(float u, float v, int w, int h) {
+    float xf = u * static_cast<float>(w) - 0.5f, yf = v * static_cast<float>(h) - 0.5f;
+    float fx = floorf(xf), fy = floorf(yf);
+    Taps t;
+    t.tx = xf - fx;
+    t.ty = yf - fy;
+    int x0 = static_cast<int>(fx), y0 = static_cast<int>(fy);
+    t.x0 = wrap_coord(x0, w);
+    t.y0 = wrap_coord(y0, h);
+    t.x1 = wrap_coord(x0 + 1, w);
+    t.y1 = wrap_coord(y0 + 1, h);
+    return t;
+}
+__device__ __forceinline__ float4 texel8(const SceneDev& sc, uint32_t word, bool srgb) {
+    uint32_t r = word & 0xffu, g = (word >> 8) & 0xffu, b = (word >> 16) & 0xffu, a = word >> 24;
+    float fa = static_cast<float>(a) / 255.0f;
+    if (srgb) return make_float4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], fa);
+    return make_float4(static_cast<float>(r) / 255.0f, static_cast<float>(g) / 255.0f, static_cast<float>(b) / 255.0f, fa);
+}
+__device__ __forceinline__ float4 sample_image(const SceneDev& sc, int image, float u, float v, bool srgb) {
+    const DevImage im = sc.images[image];
+    const Taps t = bilinear_taps(u, v, im.width, im.height);
+    const uint32_t* px = sc.texels + im.offset;
+    const uint32_t w00 = px[t.y0 * im.width + t.x0], w10 = px[t.y0 * im.width + t.x1], w01 = px[t.y1 * im.width + t.x0],
+                   w11 = px[t.y1 * im.width + t.x1];
+    const float4 top = mix4(texel8(sc, w00, srgb), texel8(sc, w10, srgb), t.tx);
+    const float4 bot = mix4(texel8(sc, w01, srgb), texel8(sc, w11, srgb), t.tx);
+    return mix4(top, bot, t.ty);
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 sample_albedo(const SceneDev& sc, const DevMaterial& m, float u, float v) {
+    float4 f = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
+    if (m.base_color_tex >= 0) f = mul4(f, sample_image(sc, m.base_color_tex, u, v, true));
+    return f;
+}
+__device__ __forceinline__ float4 sample_orm(const SceneDev& sc, const DevMaterial& m, float u, float v) {
+    float4 f = make_float4(1.0f, m.roughness, m.metallic, 1.0f);
+    if (m.mr_tex >= 0) f = mul4(f, sample_image(sc, m.mr_tex, u, v, false));
+    return f;
+}
+__device__ __forceinline__ float4 sample_normals(const SceneDev& sc, const DevMaterial& m, float u, float v) {
+    if (m.normal_tex >= 0) return sample_image(sc, m.normal_tex, u, v, false);
+    return make_float4(0.5f, 0.5f, 1.0f, 0.0f);
+}
+__device__ __forceinline__ f3 sample_emissive(const SceneDev& sc, const DevMaterial& m, float u, float v) {
+    float4 f = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], 1.0f);
+    if (m.emissive_tex >= 0) f = mul4(f, sample_image(sc, m.emissive_tex, u, v, true));
+    return f3{f.x * m.emissive_strength, f.y * m.emissive_strength, f.z * m.emissive_strength};
+}
+__device__ __forceinline__ float sample_transmission(const SceneDev& sc, const DevMaterial& m, float u, float v) {
+    float f = m.transmission;
+    if (m.transmission_tex >= 0) f *= sample_image(sc, m.transmission_tex, u, v, false).x;
+    return f;
+}
+__device__ __forceinline__ f3 sample_environment(const SceneDev& sc, f3 dir) {  // brdf.cc:62-69
+    float u = (pt_atan2(-dir.z, -dir.x) + sc.env_rot) * (1.0f / kPiF);
+    float v = (-2.0f * pt_asin(dir.y)) * (1.0f / kPiF);
+    u = u * 0.5f + 0.5f;
+    v = v * 0.5f + 0.5f;
+    const Taps t = bilinear_taps(u, v, sc.env_w, sc.env_h);
+    const float4 c00 = sc.env[t.y0 * sc.env_w + t.x0], c10 = sc.env[t.y0 * sc.env_w + t.x1],
+                 c01 = sc.env[t.y1 * sc.env_w + t.x0], c11 = sc.env[t.y1 * sc.env_w + t.x1];
+    const float4 r = mix4(mix4(c00, c10, t.tx), mix4(c01, c11, t.tx), t.ty);
+    return f3{r.x, r.y, r.z};
+}
+
+// ---------------------------------------------------------------------------------------------
+// shading helpers (ray_program.cc:16-142)
+// ---------------------------------------------------------------------------------------------
+struct VertexD {
+    f3 position, normal;
+    float4 tangent;
+    float u, v;
+};
+__device__ __forceinline__ VertexD load_vertex(const SceneDev& sc, uint32_t idx) {
+    const float4* p = sc.vertices + static_cast<size_t>(idx) * 3;
+    const float4 a = p[0], b = p[1], c = p[2];
+    VertexD r;
+    r.position = f3{a.x, a.y, a.z};
+    r.normal = f3{a.w, b.x, b.y};
+    r.tangent = make_float4(b.z, b.w, c.x, c.y);
+    r.u = c.z;
+    r.v = c.w;
+    return r;
+}
+__device__ __forceinline__ float lin3(float a, float b, float c, float A, float B, float C) { return a * A + b * B + c * C; }
+__device__ __forceinline__ f3 lin3(f3 a, f3 b, f3 c, float A, float B, float C) { return a * A + b * B + c * C; }
+__device__ __forceinline__ f3 cos_dir(float xi_x, float xi_y) {  // ImportanceSampleCosDir
+    float c = sqrtf(1.0f - xi_x), s = sqrtf(xi_x);
+    float sp, cp;
+    pt_sincos(2.0f * xi_y * kPiF, &sp, &cp);
+    return f3{s * cp, s * sp, c};
+}
+__device__ __forceinline__ f3 ggx_dir(float xi_x, float xi_y, float a) {  // importanceSampleGGX
+    float c2 = (1.0f - xi_x) / (1.0f + (a * a - 1.0f) * xi_x);
+    float c = sqrtf(c2), s = sqrtf(1.0f - c2);
+    float sp, cp;
+    pt_sincos(2.0f * xi_y * kPiF, &sp, &cp);
+    return f3{s * cp, s * sp, c};
+}
+__device__ __forceinline__ f3 fresnel_schlick(f3 f0, f3 f90, float c) {
+    float x = 1.0f - c;
+    float x2 = x * x;
+    float x5 = x2 * x2 * x;
+    return mix3(f0, f90, x5);
+}
+__device__ __forceinline__ float v_smith_ggx(float NoV, float NoL, float a) {  // V_SmithGGXCorrelated (2/(..): sic)
+    float a2 = a * a;
+    float gv = NoL * sqrtf((-NoV * a2 + NoV) * NoV + a2);
+    float gl = NoV * sqrtf((-NoL * a2 + NoL) * NoL + a2);
+    return 2.0f / (gv + gl);
+}
+__device__ __forceinline__ f3 reflect3(f3 I, f3 N) { return I - N * dot3(N, I) * 2.0f; }
+__device__ __forceinline__ f3 refract3(f3 I, f3 N, float eta) {
+    float d = dot3(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k >= 0.0f) return eta * I - (eta * d + sqrtf(k)) * N;
+    return mk3(0.0f);
+}
+struct Tbn {
+    f3 t, b, n;
+};
+__device__ __forceinline__ Tbn make_tbn(f3 tangent, f3 bitangent, f3 normal) {  // construct_TBN
+    Tbn r;
+    r.n = normalize3(normal);
+    r.t = normalize3(tangent - r.n * dot3(r.n, tangent));
+    r.b = normalize3(bitangent - r.n * dot3(r.n, bitangent) - r.t * dot3(r.t, bitangent));
+    return r;
+}
+__device__ __forceinline__ f3 normal_map_to_world(float4 s, const Tbn& tbn) {  // normal_map_sample_to_world
+    f3 n = f3{fmaf(s.x, 2.0f, -1.0f), fmaf(s.y, 2.0f, -1.0f), fmaf(s.z, 2.0f, -1.0f)};
+    n.y *= -1.0f;
+    return mul_tbn(tbn.t, tbn.b, tbn.n, n);
+}
+
+struct ShadePoint {
+    VertexD p;           // interpolated vertex; normal/tangent in world space after to_world()
+    f3 p1, p2, p3;       // object-space corner positions (geometric normal)
+    f3 bitangent;
+    uint32_t material;
+    const DevObject* obj;
+};
+// get_vertex_data + interpolate_vertex_data + convert_normals_to_world_space (ray_program.cc:75-101)
+__device__ __forceinline__ ShadePoint fetch_point(const SceneDev& sc, uint32_t object, uint32_t tri, float A, float B) {
+    ShadePoint sp;
+    sp.obj = sc.objects + object;
+    const DevMesh mesh = sc.meshes[sp.obj->mesh_index];
+    const uint32_t* ix = sc.indices + mesh.first_index + tri;
+    const VertexD v1 = load_vertex(sc, mesh.first_vertex + ix[0]);
+    const VertexD v2 = load_vertex(sc, mesh.first_vertex + ix[1]);
+    const VertexD v3 = load_vertex(sc, mesh.first_vertex + ix[2]);
+    const float C = 1.0f - A - B;
+    sp.p.position = lin3(v1.position, v2.position, v3.position, A, B, C);
+    sp.p.normal = lin3(v1.normal, v2.normal, v3.normal, A, B, C);
+    sp.p.tangent = make_float4(lin3(v1.tangent.x, v2.tangent.x, v3.tangent.x, A, B, C),
+                               lin3(v1.tangent.y, v2.tangent.y, v3.tangent.y, A, B, C),
+                               lin3(v1.tangent.z, v2.tangent.z, v3.tangent.z, A, B, C),
+                               lin3(v1.tangent.w, v2.tangent.w, v3.tangent.w, A, B, C));
+    sp.p.u = lin3(v1.u, v2.u, v3.u, A, B, C);
+    sp.p.v = lin3(v1.v, v2.v, v3.v, A, B, C);
+    sp.p1 = v1.position; sp.p2 = v2.position; sp.p3 = v3.position;
+    sp.material = mesh.material;
+    return sp;
+}
+__device__ __forceinline__ void normals_to_world(ShadePoint& sp) {
+    const float sign = sp.p.tangent.w;
+    const f3 t = xform(sp.obj->model, f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, 0.0f);
+    sp.p.tangent = make_float4(t.x, t.y, t.z, 0.0f);
+    sp.p.normal = xform(sp.obj->normal, sp.p.normal, 0.0f);
+    sp.bitangent = cross3(sp.p.normal, t) * sign;
+}
+
+// wavefront-level append of up to NSLOT rays per lane: slot-major order inside a wave keeps rays of
+// one lobe contiguous; one atomic per wave
+template <int NSLOT>
+__device__ __forceinline__ void append_rays(const bool (&has)[NSLOT], const float4 (&o)[NSLOT], const float4 (&d)[NSLOT],
+                                            const float4 (&p)[NSLOT], RayQueue out, uint32_t* out_count) {
+    const uint32_t lane_id = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane_id) - 1ull;
+    uint32_t offs[NSLOT];
+    uint32_t total = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const unsigned long long m = __ballot(has[s]);
+        offs[s] = total + __popcll(m & lt);
+        total += __popcll(m);
+    }
+    uint32_t base = 0;
+    if (lane_id == 0 && total) base = atomicAdd(out_count, total);
+    base = __shfl(base, 0);
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        if (has[s]) {
+            const uint32_t dst = base + offs[s];
+            out.o[dst] = o[s];
+            out.d[dst] = d[s];
+            out.p[dst] = p[s];
+        }
+    }
+}
+
+__device__ __forceinline__ void add_radiance(FrameDev fb, uint32_t pid, f3 c) {
+    if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f) {
+        atomicAdd(fb.sum + pid, c.x);
+        atomicAdd(fb.sum + fb.stride + pid, c.y);
+        atomicAdd(fb.sum + 2u * fb.stride + pid, c.z);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: RayCaster (ray_program.cc:150-163)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
+                                                               FrameDev fb) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 ro = rays.o[i], rd = rays.d[i];
+    const float4 h0 = hits.h0[i];
+    const uint32_t h1 = hits.h1[i];
+    f3 c;
+    if (!(h1 & 0x80000000u)) {
+        c = sample_environment(sc, ld3(rd));
+    } else {
+        const uint32_t object = h1 & 0x3fffffffu;
+        const DevMesh mesh = sc.meshes[sc.objects[object].mesh_index];
+        const uint32_t* ix = sc.indices + mesh.first_index + __float_as_uint(h0.w);
+        const float4 c1 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[0]) * 3 + 2];
+        const float4 c2 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[1]) * 3 + 2];
+        const float4 c3 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[2]) * 3 + 2];
+        const float A = h0.y, B = h0.z, C = 1.0f - A - B;
+        const float u = lin3(c1.z, c2.z, c3.z, A, B, C), v = lin3(c1.w, c2.w, c3.w, A, B, C);
+        const float4 a = sample_albedo(sc, sc.materials[mesh.material], u, v);
+        c = f3{a.x, a.y, a.z};
+    }
+    add_radiance(fb, __float_as_uint(ro.w), c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: AmbientOcclusion (ray_program.cc:172-225)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
+                                                          RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb,
+                                                          uint32_t ao_samples) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool spawn = false;
+    f3 new_pos = mk3(0.0f);
+    Tbn tbn{mk3(0.0f), mk3(0.0f), mk3(0.0f)};
+    float jx = 0.0f, jy = 0.0f;
+    uint32_t pid = 0, key = 0, new_depth = 0;
+    if (i < n) {
+        const float4 ro = rays.o[i], rd = rays.d[i], rp = rays.p[i];
+        const float4 h0 = hits.h0[i];
+        const uint32_t h1 = hits.h1[i];
+        pid = __float_as_uint(ro.w);
+        key = __float_as_uint(rp.w);
+        const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
+        if (!(h1 & 0x80000000u)) {
+            add_radiance(fb, pid, f3{rp.x, rp.y, rp.z});  // miss: return the payload
+        } else if (depth != 0) {
+            ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
+            normals_to_world(sp);
+            const DevMaterial& mat = sc.materials[sp.material];
+            if ((h1 & 0x40000000u) && mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;
+            tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
+            const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
+            if (nm.w != 0.0f) {
+                const f3 nv = normal_map_to_world(nm, tbn);
+                tbn = make_tbn(tbn.t, tbn.b, nv);
+            }
+            const f3 ws_pos = ld3(ro) + ld3(rd) * h0.x;
+            new_pos = ws_pos + sp.p.normal * 1e-5f;
+            new_depth = (depth - 1u) & 0xffu;
+            jx = rng_uniform(key, 0);
+            jy = rng_uniform(key, 1);
+            spawn = true;
+        }
+    }
+    // every spawning lane emits ao_samples rays: wave-level reservation, sample-major order
+    const unsigned long long mask = __ballot(spawn);
+    if (!mask) return;
+    const uint32_t lane_id = threadIdx.x & 63u;
+    const uint32_t n_spawn = __popcll(mask);
+    uint32_t base = 0;
+    if (lane_id == 0) base = atomicAdd(out_count, n_spawn * ao_samples);
+    base = __shfl(base, 0);
+    if (!spawn) return;
+    const uint32_t rank = __popcll(mask & ((1ull << lane_id) - 1ull));
+    const float inv = 1.0f / static_cast<float>(ao_samples);
+    for (uint32_t s = 0; s < ao_samples; ++s) {
+        // fibonacci2D + Cranley-Patterson shift (ray_program.cc:212-215; brdf.cc:73-78)
+        const float fi = static_cast<float>(s);
+        float rx = (fi + 0.5f) * inv;
+        float gy = (fi + 1.0f) * 1.618034f;
+        float ry = gy - floorf(gy);  // fmod(x, 1) for x >= 0
+        rx = rx + jx; rx = rx - floorf(rx);
+        ry = ry + jy; ry = ry - floorf(ry);
+        const f3 dir = mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(rx, ry));
+        const uint32_t dst = base + s * n_spawn + rank;
+        out.o[dst] = make_float4(new_pos.x, new_pos.y, new_pos.z, __uint_as_float(pid));
+        out.d[dst] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(new_depth | 0x100u));
+        out.p[dst] = make_float4(inv, inv, inv, __uint_as_float(rng_child(key, LOBE_AO0 + s)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// shade: PBR (ray_program.cc:234-391)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
+                                                           RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
+    float4 no[4], nd[4], np[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) no[s] = nd[s] = np[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    if (i < n) {
+        const float4 ro = rays.o[i], rd = rays.d[i], rp = rays.p[i];
+        const float4 h0 = hits.h0[i];
+        const uint32_t h1 = hits.h1[i];
+        const uint32_t pid = __float_as_uint(ro.w);
+        const uint32_t key = __float_as_uint(rp.w);
+        const uint32_t flags = __float_as_uint(rd.w);
+        const uint32_t depth = flags & 0xffu;
+        const f3 payload = f3{rp.x, rp.y, rp.z};
+        const f3 dir = ld3(rd);
+        f3 radiance = mk3(0.0f);
+        if (!(h1 & 0x80000000u)) {
+            radiance = payload * sample_environment(sc, dir);
+        } else {
+            const bool backface = (h1 & 0x40000000u) != 0;
+            ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
+            sp.p.position = xform(sp.obj->model, sp.p.position, 1.0f);
+            normals_to_world(sp);
+            const DevMaterial& mat = sc.materials[sp.material];
+            bool exiting = false;
+            if (backface) {
+                if (mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;
+                else if (mat.has_volume) exiting = true;
+            }
+            const float4 albedo = sample_albedo(sc, mat, sp.p.u, sp.p.v);
+            float alpha = albedo.w;
+            if (!mat.alpha_blending) alpha = (alpha < mat.alpha_cutoff) ? 0.0f : 1.0f;
+            if (alpha != 1.0f) {  // pass-through ray: same direction and depth (ray_program.cc:265-271)
+                const f3 org = sp.p.position + (exiting ? 1.0f : -1.0f) * sp.p.normal * 1e-5f;
+                const f3 pl = payload * (1.0f - alpha);
+                has[0] = true;
+                no[0] = make_float4(org.x, org.y, org.z, ro.w);
+                nd[0] = rd;
+                np[0] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_PASS)));
+            }
+            if (alpha != 0.0f) {
+                f3 atten = mk3(1.0f);
+                if (exiting) {  // volume absorption on the segment that leaves the volume (:278-279)
+                    const f3 e = f3{-mat.attenuation[0], -mat.attenuation[1], -mat.attenuation[2]} * h0.x;
+                    atten = f3{sel_min(pt_exp(e.x), 1.0f), sel_min(pt_exp(e.y), 1.0f), sel_min(pt_exp(e.z), 1.0f)};
+                }
+                const f3 emissive = sample_emissive(sc, mat, sp.p.u, sp.p.v);
+                radiance = payload * emissive * atten * alpha;
+                if (depth != 0) {
+                    const f3 v = -dir;
+                    const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
+                    // handle_TBN_creation (ray_program.cc:121-142)
+                    Tbn tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
+                    const bool has_map = (nm.w != 0.0f);
+                    f3 nv = has_map ? normal_map_to_world(nm, tbn) : tbn.n;
+                    const bool impossible = dot3(exiting ? -v : v, nv) < 0.0f;
+                    if (impossible) {
+                        f3 g = normalize3(cross3(sp.p2 - sp.p1, sp.p3 - sp.p1));
+                        if (mat.double_sided && backface) g = g * -1.0f;
+                        nv = xform(sp.obj->normal, g, 0.0f);
+                    }
+                    if (has_map || impossible) tbn = make_tbn(tbn.t, tbn.b, nv);
+
+                    const float transmission = sample_transmission(sc, mat, sp.p.u, sp.p.v);
+                    const float4 orm = sample_orm(sc, mat, sp.p.u, sp.p.v);
+                    const f3 alb = f3{albedo.x, albedo.y, albedo.z};
+                    const f3 diffuse_color = (1.0f - orm.z) * alb;
+                    const f3 f0 = mix3(mk3(mat.f0), alb, orm.z);
+                    const f3 f90 = mk3(1.0f);
+                    const float a_lin = orm.y * orm.y;
+                    const uint32_t nflags = (depth - 1u) & 0xffu;
+                    const float u0 = rng_uniform(key, 0), u1 = rng_uniform(key, 1), u2 = rng_uniform(key, 2),
+                                u3 = rng_uniform(key, 3);
+
+                    if (any_ne(diffuse_color * (1.0f - transmission), mk3(0.0f))) {  // diffuse lobe (:306-323)
+                        const f3 l = normalize3(mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(u0, u1)));
+                        const f3 h = normalize3(v + l);
+                        const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
+                        const f3 F = mk3(1.0f) - fresnel_schlick(f0, f90, LdH);
+                        const f3 org = sp.p.position + sp.p.normal * 1e-5f;
+                        const f3 pl = F * diffuse_color * (1.0f - transmission) * atten * payload * alpha;
+                        has[1] = true;
+                        no[1] = make_float4(org.x, org.y, org.z, ro.w);
+                        nd[1] = make_float4(l.x, l.y, l.z, __uint_as_float(nflags));
+                        np[1] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_DIFFUSE)));
+                    }
+                    {   // micro-normal shared by transmission and reflection (:324-389)
+                        f3 m = mul_tbn(tbn.t, tbn.b, tbn.n, ggx_dir(u2, u3, a_lin));
+                        f3 N = tbn.n;
+                        f3 offset_dir = sp.p.normal;
+                        if (exiting) {
+                            m = m * -1.0f;
+                            N = N * -1.0f;
+                            offset_dir = offset_dir * -1.0f;
+                        }
+                        const float eta = (!exiting) ? 1.0f / mat.ior : mat.ior;
+                        f3 l = refract3(-v, m, eta);
+                        const float VdN = clampf(dot3(N, v), 1e-8f, 1.0f);
+                        const float VdM = clampf(dot3(v, m), 0.0f, 1.0f);
+                        const float LdM = clampf(dot3(l, -m), 0.0f, 1.0f);
+                        const f3 F = fresnel_schlick(f0, f90, (!exiting) ? VdM : LdM);
+                        if (any_ne(diffuse_color * transmission, mk3(0.0f)) && any_ne(l, mk3(0.0f))) {
+                            const f3 h = normalize3(-(eta * v + l));
+                            const float LdN = clampf(dot3(-N, l), 0.0f, 1.0f);
+                            const float G = v_smith_ggx(VdN, LdN, a_lin);
+                            const float NdM = clampf(dot3(N, m), 1e-8f, 1.0f);
+                            const float VdH = clampf(dot3((!exiting) ? v : -v, h), 0.0f, 1.0f);
+                            const float w = G * VdH * LdN / NdM;
+                            f3 brdf = (mk3(1.0f) - F) * w;
+                            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
+                            const f3 org = sp.p.position - offset_dir * 1e-5f;
+                            const f3 ln = normalize3(l);
+                            const f3 pl = diffuse_color * transmission * atten * brdf * payload * alpha;
+                            has[2] = true;
+                            no[2] = make_float4(org.x, org.y, org.z, ro.w);
+                            nd[2] = make_float4(ln.x, ln.y, ln.z, __uint_as_float(nflags));
+                            np[2] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_TRANSMIT)));
+                        }
+                        {   // specular reflection (:371-388)
+                            const f3 h = m;
+                            l = normalize3(reflect3(-v, h));
+                            const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
+                            const float LdN = clampf(dot3(N, l), 0.0f, 1.0f);
+                            const float NdH = clampf(dot3(N, h), 1e-8f, 1.0f);
+                            const float G = v_smith_ggx(VdN, LdN, a_lin);
+                            const float w = G * LdN * LdH / NdH;
+                            f3 brdf = F * w;
+                            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
+                            const f3 org = sp.p.position + offset_dir * 1e-5f;
+                            const f3 pl = atten * brdf * payload * alpha;
+                            has[3] = true;
+                            no[3] = make_float4(org.x, org.y, org.z, ro.w);
+                            nd[3] = make_float4(l.x, l.y, l.z, __uint_as_float(nflags));
+                            np[3] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_REFLECT)));
+                        }
+                    }
+                }
+            }
+        }
+        add_radiance(fb, pid, radiance);
+    }
+    append_rays<4>(has, no, nd, np, out, out_count);
+}
+
+// ---------------------------------------------------------------------------------------------
+// framebuffer
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void clear_kernel(float4* __restrict__ p, uint64_t n4) {
+    uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * kBlock;
+    for (; i < n4; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+__global__ __launch_bounds__(kBlock) void resolve_kernel(FrameDev fb, CameraDev cam, float4* __restrict__ out, float divisor,
+                                                         float alpha) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t npix = static_cast<uint32_t>(cam.width) * cam.height;
+    if (i >= npix) return;
+    const uint32_t x = i % cam.width, y = i / cam.width;
+    const uint32_t tile = (y / kTile) * cam.tiles_x + (x / kTile);
+    const uint32_t pid = tile * 64u + (y % kTile) * 8u + (x % kTile);
+    out[i] = make_float4(fb.sum[pid] / divisor, fb.sum[fb.stride + pid] / divisor, fb.sum[2u * fb.stride + pid] / divisor, alpha);
+}
+__global__ __launch_bounds__(kBlock) void divide_rgba_kernel(float4* __restrict__ p, uint64_t n, float divisor) {
+    const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 v = p[i];
+    p[i] = make_float4(v.x / divisor, v.y / divisor, v.z / divisor, 1.0f);
+}
+__global__ __launch_bounds__(kBlock) void pack_rays_kernel(const float* __restrict__ o, const float* __restrict__ d,
+                                                           const uint8_t* __restrict__ any, uint32_t n, RayQueue out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    out.o[i] = make_float4(o[3 * i], o[3 * i + 1], o[3 * i + 2], __uint_as_float(i));
+    out.d[i] = make_float4(d[3 * i], d[3 * i + 1], d[3 * i + 2], __uint_as_float((any && any[i]) ? 0x100u : 0u));
+    out.p[i] = make_float4(1.f, 1.f, 1.f, 0.f);
+}
+
+inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
+                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n, RayQueue out,
+                     uint32_t* out_count) {
+    if (!n) return;
+    hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
+                       sample_step, max_bounces, seed, first, n, out, out_count);
+}
+void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
+                   uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters) {
+    if (!n) return;
+    if (counters)
+        hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
+                           hits.h1, spill, spill_depth, spill_stride, counters);
+    else
+        hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
+                           hits.h1, spill, spill_depth, spill_stride, counters);
+}
+void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples) {
+    if (!n) return;
+    const dim3 grid(blocks_for(n)), block(kBlock);
+    if (program == 1)
+        hipLaunchKernelGGL(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
+    else if (program == 2)
+        hipLaunchKernelGGL(shade_pbr_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
+    else
+        hipLaunchKernelGGL(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
+}
+void launch_clear(hipStream_t st, float* p, uint64_t n) {
+    if (!n) return;
+    const uint64_t n4 = n / 4;  // callers pad to a multiple of 4 floats
+    uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n4 + kBlock - 1) / kBlock, 2048));
+    hipLaunchKernelGGL(clear_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, reinterpret_cast<float4*>(p), n4);
+}
+void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha) {
+    const uint64_t npix = static_cast<uint64_t>(cam.width) * cam.height;
+    hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(npix)), dim3(kBlock), 0, st, fb, cam,
+                       reinterpret_cast<float4*>(out_rgba), divisor, alpha);
+}
+void launch_divide_rgba(hipStream_t st, float* rgba, uint64_t n_pixels, float divisor) {
+    if (!n_pixels) return;
+    hipLaunchKernelGGL(divide_rgba_kernel, dim3(blocks_for(n_pixels)), dim3(kBlock), 0, st, reinterpret_cast<float4*>(rgba),
+                       n_pixels, divisor);
+}
+void launch_pack_rays(hipStream_t st, const float* origins, const float* directions, const uint8_t* any_hit, uint32_t n,
+                      RayQueue out) {
+    if (!n) return;
+    hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, origins, directions, any_hit, n, out);
+}
+
+}  // namespace ptd

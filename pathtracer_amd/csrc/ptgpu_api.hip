@@ -1,0 +1,807 @@
+// ptgpu_api.hip — implementation of the C ABI declared in include/ptgpu.h: context, scene upload and
+// the host-side wavefront scheduler that drives generate -> extend -> shade until every ray queue drains.
+//
+// Scheduling.  The reference traces each camera sample depth first with a per-thread LIFO of rays
+// (renderer.cc:100-117).  Here the LIFO holds ray *segments* of up to `chunk` rays: the newest segment
+// is popped, extended and shaded; the rays it spawns become new segments on top.  Segments of
+// alternating generations live in two bump-allocated pools, so the pool a segment came from is always
+// freed from its top and live rays stay bounded by (fan-out x chunk) per generation however strongly
+// the PBR estimator branches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ptgpu.h"
+#include "pt_bvh.h"
+#include "pt_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// ---- host vector math with glm's operation order (camera state only) -----------------------------
+struct H3 {
+    float x, y, z;
+};
+inline H3 sub(H3 a, H3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 add(H3 a, H3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline float hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline H3 hnorm(H3 v) {
+    float s = 1.0f / std::sqrt(hdot(v, v));
+    return {v.x * s, v.y * s, v.z * s};
+}
+struct Mat4 {
+    float m[16];  // column-major: m[c * 4 + r]
+    float& at(int c, int r) { return m[c * 4 + r]; }
+    float at(int c, int r) const { return m[c * 4 + r]; }
+};
+Mat4 mat_mul(const Mat4& a, const Mat4& b) {  // glm: ((a0*b0 + a1*b1) + a2*b2) + a3*b3 per column
+    Mat4 r;
+    for (int j = 0; j < 4; ++j)
+        for (int i = 0; i < 4; ++i) {
+            float t = a.at(0, i) * b.at(j, 0);
+            t = t + a.at(1, i) * b.at(j, 1);
+            t = t + a.at(2, i) * b.at(j, 2);
+            t = t + a.at(3, i) * b.at(j, 3);
+            r.at(j, i) = t;
+        }
+    return r;
+}
+Mat4 mat_inverse(const Mat4& m) {  // glm::inverse(mat4): cofactors, then one reciprocal determinant
+    auto e = [&](int c, int r) { return m.at(c, r); };
+    const float c00 = e(2, 2) * e(3, 3) - e(3, 2) * e(2, 3), c02 = e(1, 2) * e(3, 3) - e(3, 2) * e(1, 3),
+                c03 = e(1, 2) * e(2, 3) - e(2, 2) * e(1, 3);
+    const float c04 = e(2, 1) * e(3, 3) - e(3, 1) * e(2, 3), c06 = e(1, 1) * e(3, 3) - e(3, 1) * e(1, 3),
+                c07 = e(1, 1) * e(2, 3) - e(2, 1) * e(1, 3);
+    const float c08 = e(2, 1) * e(3, 2) - e(3, 1) * e(2, 2), c10 = e(1, 1) * e(3, 2) - e(3, 1) * e(1, 2),
+                c11 = e(1, 1) * e(2, 2) - e(2, 1) * e(1, 2);
+    const float c12 = e(2, 0) * e(3, 3) - e(3, 0) * e(2, 3), c14 = e(1, 0) * e(3, 3) - e(3, 0) * e(1, 3),
+                c15 = e(1, 0) * e(2, 3) - e(2, 0) * e(1, 3);
+    const float c16 = e(2, 0) * e(3, 2) - e(3, 0) * e(2, 2), c18 = e(1, 0) * e(3, 2) - e(3, 0) * e(1, 2),
+                c19 = e(1, 0) * e(2, 2) - e(2, 0) * e(1, 2);
+    const float c20 = e(2, 0) * e(3, 1) - e(3, 0) * e(2, 1), c22 = e(1, 0) * e(3, 1) - e(3, 0) * e(1, 1),
+                c23 = e(1, 0) * e(2, 1) - e(2, 0) * e(1, 1);
+    const float f0[4] = {c00, c00, c02, c03}, f1[4] = {c04, c04, c06, c07}, f2[4] = {c08, c08, c10, c11},
+                f3[4] = {c12, c12, c14, c15}, f4[4] = {c16, c16, c18, c19}, f5[4] = {c20, c20, c22, c23};
+    const float v0[4] = {e(1, 0), e(0, 0), e(0, 0), e(0, 0)}, v1[4] = {e(1, 1), e(0, 1), e(0, 1), e(0, 1)},
+                v2[4] = {e(1, 2), e(0, 2), e(0, 2), e(0, 2)}, v3[4] = {e(1, 3), e(0, 3), e(0, 3), e(0, 3)};
+    const float sa[4] = {+1, -1, +1, -1}, sb[4] = {-1, +1, -1, +1};
+    Mat4 inv;
+    for (int i = 0; i < 4; ++i) {
+        inv.at(0, i) = ((v1[i] * f0[i] - v2[i] * f1[i]) + v3[i] * f2[i]) * sa[i];
+        inv.at(1, i) = ((v0[i] * f0[i] - v2[i] * f3[i]) + v3[i] * f4[i]) * sb[i];
+        inv.at(2, i) = ((v0[i] * f1[i] - v1[i] * f3[i]) + v3[i] * f5[i]) * sa[i];
+        inv.at(3, i) = ((v0[i] * f2[i] - v1[i] * f4[i]) + v2[i] * f5[i]) * sb[i];
+    }
+    const float d0 = e(0, 0) * inv.at(0, 0), d1 = e(0, 1) * inv.at(1, 0), d2 = e(0, 2) * inv.at(2, 0),
+                d3 = e(0, 3) * inv.at(3, 0);
+    const float ood = 1.0f / ((d0 + d1) + (d2 + d3));
+    for (float& v : inv.m) v = v * ood;
+    return inv;
+}
+
+// ---- device memory ---------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    template <typename T>
+    T* as() const { return static_cast<T*>(p); }
+};
+
+struct Segment {
+    int pool;
+    uint64_t offset;
+    uint32_t count;
+};
+struct Pool {
+    DevBuf o, d, p;
+    uint64_t cap = 0, top = 0;
+    ptd::RayQueue at(uint64_t off) const { return {o.as<float4>() + off, d.as<float4>() + off, p.as<float4>() + off}; }
+};
+
+}  // namespace
+
+struct ptgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    ptgpu_settings settings{};        // current
+    ptgpu_settings scene_settings{};  // as of the last load_scene (AS type, leaf size, program, env rotation)
+    bool scene_loaded = false, camera_set = false;
+
+    // scene
+    DevBuf nodes, tris, instances, xforms, objects, meshes, vertices, indices, materials, images, texels, env, lut;
+    ptd::SceneDev scene{};
+    std::vector<ptgpu_bvh_info> bvh_info;
+    std::vector<uint32_t> object_mesh;  // object -> mesh index (for hit dumps)
+    uint32_t max_depth = 0;
+    float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
+
+    // camera (Renderer::NDC2WorldMatrix_, origin_)
+    float ndc2world[16];
+    float origin[3];
+
+    // work memory
+    uint32_t chunk = 1u << 21;
+    Pool pools[2];
+    DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba;
+    uint32_t* host_counter = nullptr;  // pinned
+    hipEvent_t ev[6] = {};
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        error = buf;
+        return code;
+    }
+};
+
+namespace {
+
+#define PT_HIP(ctx, call)                                                                               \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return (ctx)->fail(PTGPU_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+int upload(ptgpu_ctx* c, DevBuf& buf, const T* src, size_t n) {
+    PT_HIP(c, buf.ensure(std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) PT_HIP(c, hipMemcpy(buf.p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PTGPU_OK;
+}
+
+float srgb_to_linear_host(float ch) {  // cpu_framebuffer.h:21-27
+    if (ch <= 0.04045f) return ch / 12.92f;
+    return std::pow((ch + 0.055f) / 1.055f, 2.4f);
+}
+
+std::vector<float> subsample_table(uint32_t spp) {  // Renderer::generate_subsample_positions, renderer.cc:135-155
+    std::vector<float> t(2 * static_cast<size_t>(spp));
+    const int root = static_cast<int>(sqrtf(static_cast<float>(spp)));
+    if (static_cast<uint32_t>(root * root) == spp) {
+        for (uint32_t i = 0; i < spp; ++i) {
+            t[2 * i] = (static_cast<float>(i / root) + 0.5f) / static_cast<float>(root);
+            t[2 * i + 1] = (static_cast<float>(i % root) + 0.5f) / static_cast<float>(root);
+        }
+    } else {
+        const float inv = 1.0f / static_cast<float>(spp);
+        for (uint32_t i = 0; i < spp; ++i) {  // fibonacci2D, brdf.cc:73-78
+            const float f = static_cast<float>(i);
+            t[2 * i] = (f + 0.5f) * inv;
+            t[2 * i + 1] = std::fmod((f + 1.0f) * 1.618034f, 1.0f);
+        }
+    }
+    return t;
+}
+
+struct FrameGeometry {
+    ptd::CameraDev cam;
+    uint32_t n_tiles;
+    uint32_t fb_stride;
+};
+FrameGeometry frame_geometry(const ptgpu_ctx* c, int w, int h) {
+    FrameGeometry g;
+    std::memcpy(g.cam.ndc2world, c->ndc2world, 64);
+    std::memcpy(g.cam.origin, c->origin, 12);
+    g.cam.inv_w = 1.0f / static_cast<float>(w);  // renderer.cc:89-90
+    g.cam.inv_h = 1.0f / static_cast<float>(h);
+    g.cam.width = w;
+    g.cam.height = h;
+    g.cam.tiles_x = (w + ptd::kTile - 1) / ptd::kTile;
+    g.cam.tiles_y = (h + ptd::kTile - 1) / ptd::kTile;
+    g.n_tiles = static_cast<uint32_t>(g.cam.tiles_x) * g.cam.tiles_y;
+    g.fb_stride = g.n_tiles * 64u;
+    return g;
+}
+
+uint32_t fanout_of(const ptgpu_settings& s) {
+    if (s.program_mode == PTGPU_PROGRAM_PBR) return 4;  // pass-through + diffuse + transmission + reflection
+    if (s.program_mode == PTGPU_PROGRAM_AO) return s.max_new_rays_per_bounce;
+    return 0;
+}
+
+int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces) {
+    const uint64_t K = c->chunk;
+    // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
+    uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
+    uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
+    const uint64_t cap_limit = (24ull << 30) / 48;  // at most 24 GiB per pool; the scheduler splits segments beyond that
+    cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
+    for (Pool& p : c->pools) {
+        if (p.cap < cap) {
+            PT_HIP(c, p.o.ensure(cap * 16));
+            PT_HIP(c, p.d.ensure(cap * 16));
+            PT_HIP(c, p.p.ensure(cap * 16));
+            p.cap = cap;
+        }
+    }
+    PT_HIP(c, c->hit0.ensure(K * 16));
+    PT_HIP(c, c->hit1.ensure(K * 4));
+    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * K * 4 + 16));
+    PT_HIP(c, c->counter.ensure(16));
+    PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
+    return PTGPU_OK;
+}
+
+struct RenderOut {
+    float* d_rgba;    // device RGBA row-major destination (may be null)
+    bool mean;        // divide by the number of samples rendered
+};
+
+// The frame loop: Renderer::render_frame (renderer.cc:77-123) as a wavefront schedule.
+int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counted, ptgpu_stats* stats, float* d_rgba,
+                bool mean) {
+    if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "render_frame: no scene loaded (a component is null)");
+    if (!c->camera_set) return c->fail(PTGPU_E_STATE, "render_frame: camera transform state not set");
+    if (width <= 0 || height <= 0) return c->fail(PTGPU_E_INVALID, "render_frame: bad framebuffer size %dx%d", width, height);
+    PT_HIP(c, hipSetDevice(c->device));
+    const ptgpu_settings s = c->settings;
+    const int program = c->scene_settings.program_mode;
+    const uint32_t spp = s.samples_per_pixel ? s.samples_per_pixel : 1;
+    const uint32_t step = s.sample_step ? s.sample_step : 1;
+    const uint32_t begin = s.sample_begin;
+    const uint32_t n_slots = begin < spp ? (spp - begin + step - 1) / step : 0;
+    ptgpu_settings fan_src = s;
+    fan_src.program_mode = program;
+    fan_src.max_new_rays_per_bounce = c->scene_settings.max_new_rays_per_bounce;
+    const uint32_t fanout = fanout_of(fan_src);
+    const uint32_t ao_samples = c->scene_settings.max_new_rays_per_bounce;
+    const uint32_t bounces = s.max_ray_bounces & 0xffu;  // static_cast<uint8_t>, renderer.cc:73
+
+    int rc = ensure_work_memory(c, fanout, bounces);
+    if (rc) return rc;
+    const FrameGeometry g = frame_geometry(c, width, height);
+    PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
+    ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride};
+    ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3);  // framebuffer.clear, renderer.cc:85
+    const std::vector<float> sub = subsample_table(spp);
+    PT_HIP(c, c->subs.ensure(sub.size() * 4));
+    PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
+    ptd::TraceCounters* d_tc = counted ? c->trace_counters.as<ptd::TraceCounters>() : nullptr;
+    if (counted) PT_HIP(c, hipMemsetAsync(d_tc, 0, sizeof(ptd::TraceCounters), st));
+
+    ptd::SceneDev sc = c->scene;
+    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
+    uint32_t* d_count = c->counter.as<uint32_t>();
+
+    ptgpu_stats out{};
+    const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
+    const uint64_t K = c->chunk;
+    PT_HIP(c, hipEventRecord(c->ev[4], st));
+    std::vector<Segment> stack;
+    float ms = 0.0f;
+    for (uint64_t first = 0; first < total; first += K) {
+        const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
+        c->pools[0].top = c->pools[1].top = 0;
+        PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
+        PT_HIP(c, hipEventRecord(c->ev[0], st));
+        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, c->pools[0].at(0),
+                             d_count);
+        PT_HIP(c, hipEventRecord(c->ev[1], st));
+        PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipStreamSynchronize(st));
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        out.generate_ms += ms;
+        const uint32_t n_cam = *c->host_counter;
+        out.camera_samples += n_cam;
+        if (!n_cam) continue;
+        c->pools[0].top = n_cam;
+        stack.push_back({0, 0, n_cam});
+
+        while (!stack.empty()) {
+            Segment seg = stack.back();
+            stack.pop_back();
+            Pool& in = c->pools[seg.pool];
+            Pool& op = c->pools[seg.pool ^ 1];
+            uint32_t n = seg.count;
+            if (fanout) {
+                const uint64_t room = (op.cap - op.top) / fanout;
+                if (room < std::min<uint64_t>(n, 64))
+                    return c->fail(PTGPU_E_NOMEM, "ray pool exhausted (%llu rays live); lower the chunk size",
+                                   static_cast<unsigned long long>(op.top));
+                if (room < n) {  // shade only the newest rays of the segment now, the rest later
+                    const uint32_t m = static_cast<uint32_t>(room);
+                    stack.push_back({seg.pool, seg.offset, n - m});
+                    seg.offset += n - m;
+                    n = m;
+                }
+            }
+            const ptd::RayQueue rq = in.at(seg.offset);
+            PT_HIP(c, hipEventRecord(c->ev[0], st));
+            ptd::launch_extend(st, sc, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, static_cast<uint32_t>(K), d_tc);
+            PT_HIP(c, hipEventRecord(c->ev[1], st));
+            if (fanout) PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
+            PT_HIP(c, hipEventRecord(c->ev[2], st));
+            ptd::launch_shade(st, program, sc, rq, n, hits, op.at(op.top), d_count, fb, ao_samples);
+            PT_HIP(c, hipEventRecord(c->ev[3], st));
+            if (fanout) PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
+            PT_HIP(c, hipStreamSynchronize(st));
+            PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            out.extend_ms += ms;
+            PT_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+            out.shade_ms += ms;
+            out.rays += n;
+            ++out.extend_launches;
+            ++out.shade_launches;
+            in.top = seg.offset;  // the popped rays were the newest of their pool
+            if (fanout) {
+                const uint32_t n_out = *c->host_counter;
+                for (uint64_t o = 0; o < n_out; o += K)
+                    stack.push_back({seg.pool ^ 1, op.top + o, static_cast<uint32_t>(std::min<uint64_t>(K, n_out - o))});
+                op.top += n_out;
+            }
+        }
+    }
+    if (d_rgba) {
+        const float n_samples = static_cast<float>(n_slots);
+        ptd::launch_resolve(st, fb, g.cam, d_rgba, mean ? n_samples : 1.0f, mean ? 1.0f : n_samples);
+    }
+    PT_HIP(c, hipEventRecord(c->ev[5], st));
+    PT_HIP(c, hipStreamSynchronize(st));
+    PT_HIP(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
+    out.total_ms = ms;
+    if (counted) {
+        ptd::TraceCounters tc;
+        PT_HIP(c, hipMemcpy(&tc, d_tc, sizeof(tc), hipMemcpyDeviceToHost));
+        out.nodes_visited = tc.nodes;
+        out.triangles_tested = tc.tris;
+        out.instances_tested = tc.inst_tested;
+        out.instances_entered = tc.inst_entered;
+    }
+    if (stats) *stats = out;
+    return PTGPU_OK;
+}
+
+void decode_hits(const ptgpu_ctx* c, const std::vector<float4>& h0, const std::vector<uint32_t>& h1, size_t n, ptgpu_hit* out) {
+    for (size_t i = 0; i < n; ++i) {
+        ptgpu_hit& h = out[i];
+        const bool hit = (h1[i] & 0x80000000u) != 0;
+        h.hit = hit ? 1u : 0u;
+        h.t = hit ? h0[i].x : INFINITY;
+        h.A = hit ? h0[i].y : 0.0f;
+        h.B = hit ? h0[i].z : 0.0f;
+        uint32_t tri;
+        std::memcpy(&tri, &h0[i].w, 4);
+        h.triangle_index = hit ? tri : 0u;
+        h.object_index = hit ? (h1[i] & 0x3fffffffu) : 0u;
+        h.mesh_index = hit ? c->object_mesh[h.object_index] : 0u;
+        h.backface = (hit && (h1[i] & 0x40000000u)) ? 1u : 0u;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptgpu_create(int device_id, ptgpu_ctx** out) {
+    if (!out) return PTGPU_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+        return PTGPU_E_NODEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        g_create_error = "device index out of range";
+        return PTGPU_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+        g_create_error = "hipGetDeviceProperties failed";
+        return PTGPU_E_NODEVICE;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
+        return PTGPU_E_NODEVICE;
+    }
+    auto ctx = std::make_unique<ptgpu_ctx>();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counter), 64) != hipSuccess) {
+        g_create_error = "stream / pinned memory creation failed";
+        return PTGPU_E_HIP;
+    }
+    for (hipEvent_t& ev : ctx->ev)
+        if (hipEventCreate(&ev) != hipSuccess) {
+            g_create_error = "hipEventCreate failed";
+            return PTGPU_E_HIP;
+        }
+    ptgpu_settings d{};
+    d.samples_per_pixel = 1;  // defaults of arguments.cc:36-101
+    d.max_ray_bounces = 4;
+    d.max_new_rays_per_bounce = 0;
+    d.max_triangles_per_bvh_leaf = 8;
+    d.program_mode = PTGPU_PROGRAM_PBR;
+    d.accel_struct_type = PTGPU_AS_BVH;
+    d.sample_step = 1;
+    ctx->settings = d;
+    if (const char* k = std::getenv("PTGPU_CHUNK")) {
+        long v = std::atol(k);
+        if (v >= 1024) ctx->chunk = static_cast<uint32_t>(std::min<long>(v, 1l << 26)) & ~63u;
+    }
+    *out = ctx.release();
+    return PTGPU_OK;
+}
+
+void ptgpu_destroy(ptgpu_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (hipEvent_t& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->host_counter) (void)hipHostFree(c->host_counter);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ptgpu_last_error(const ptgpu_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
+    if (!c || !s) return PTGPU_E_INVALID;
+    if (s->program_mode < 0 || s->program_mode > 2 || s->accel_struct_type < 0 || s->accel_struct_type > 1)
+        return c->fail(PTGPU_E_INVALID, "set_render_settings: program_mode / accel_struct_type out of range");
+    c->settings = *s;
+    return PTGPU_OK;
+}
+int ptgpu_get_render_settings(const ptgpu_ctx* c, ptgpu_settings* out) {
+    if (!c || !out) return PTGPU_E_INVALID;
+    *out = c->settings;
+    return PTGPU_OK;
+}
+
+int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap* env) {
+    if (!c || !model) return PTGPU_E_INVALID;
+    PT_HIP(c, hipSetDevice(c->device));
+    c->scene_loaded = false;
+    // ---- validate what the kernels index with ----
+    for (uint32_t i = 0; i < model->n_meshes; ++i) {
+        const ptgpu_mesh& m = model->meshes[i];
+        if (m.n_indices % 3 != 0) return c->fail(PTGPU_E_INVALID, "mesh %u: index count %u is not a multiple of 3", i, m.n_indices);
+        if (static_cast<uint64_t>(m.first_vertex) + m.n_vertices > model->n_vertices ||
+            static_cast<uint64_t>(m.first_index) + m.n_indices > model->n_indices)
+            return c->fail(PTGPU_E_INVALID, "mesh %u: vertex/index range outside the model arrays", i);
+        if (m.material_index >= model->n_materials) return c->fail(PTGPU_E_INVALID, "mesh %u: material index out of range", i);
+        for (uint32_t k = 0; k < m.n_indices; ++k)
+            if (model->indices[m.first_index + k] >= m.n_vertices)
+                return c->fail(PTGPU_E_INVALID, "mesh %u: index %u out of range", i, k);
+    }
+    for (uint32_t i = 0; i < model->n_objects; ++i)
+        if (model->objects[i].mesh_index >= model->n_meshes) return c->fail(PTGPU_E_INVALID, "object %u: mesh index out of range", i);
+    if (model->n_objects >= (1u << 30)) return c->fail(PTGPU_E_INVALID, "too many objects");
+    for (uint32_t i = 0; i < model->n_materials; ++i) {
+        const ptgpu_material& m = model->materials[i];
+        const int32_t tex[5] = {m.base_color_texture, m.metallic_roughness_texture, m.normal_texture, m.transmission_texture,
+                                m.emissive_texture};
+        for (int32_t t : tex)
+            if (t >= static_cast<int32_t>(model->n_images)) return c->fail(PTGPU_E_INVALID, "material %u: texture index out of range", i);
+    }
+    for (uint32_t i = 0; i < model->n_images; ++i) {
+        const ptgpu_image& im = model->images[i];
+        if (im.width <= 0 || im.height <= 0 || im.texel_offset + static_cast<uint64_t>(im.width) * im.height > model->n_texels)
+            return c->fail(PTGPU_E_INVALID, "image %u: bad size or texel range", i);
+    }
+    if (model->n_texels >= (1ull << 32)) return c->fail(PTGPU_E_INVALID, "texel pool too large");
+
+    const ptgpu_settings s = c->settings;
+    const bool naive = s.accel_struct_type == PTGPU_AS_NAIVE;
+    const uint32_t max_leaf = s.max_triangles_per_bvh_leaf ? s.max_triangles_per_bvh_leaf : 1;
+
+    // ---- acceleration structure (BVH_AS::BVH_AS, acceleration_structure.cc:352-390) ----
+    pth::InstanceTable table;
+    pth::build_instances(*model, table);
+    std::vector<ptd::DevNode> all_nodes;
+    std::vector<ptd::DevTri> all_tris;
+    std::vector<uint32_t> mesh_root(model->n_meshes);
+    c->bvh_info.assign(model->n_meshes, ptgpu_bvh_info{});
+    c->max_depth = 0;
+    for (uint32_t i = 0; i < model->n_meshes; ++i) {
+        const ptgpu_mesh& m = model->meshes[i];
+        pth::MeshTree tree;
+        pth::build_mesh_tree(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf, naive, tree);
+        if (all_tris.size() + tree.tris.size() >= (1ull << 31) || all_nodes.size() + tree.nodes.size() >= (1ull << 31))
+            return c->fail(PTGPU_E_INVALID, "scene exceeds 2^31 triangles or nodes");
+        pth::relocate(tree, static_cast<uint32_t>(all_nodes.size()), static_cast<uint32_t>(all_tris.size()));
+        mesh_root[i] = tree.root;
+        c->bvh_info[i] = tree.info;
+        c->max_depth = std::max(c->max_depth, tree.info.max_depth);
+        all_nodes.insert(all_nodes.end(), tree.nodes.begin(), tree.nodes.end());
+        all_tris.insert(all_tris.end(), tree.tris.begin(), tree.tris.end());
+    }
+    for (ptd::DevXform& xf : table.xforms) {
+        xf.root = mesh_root[xf.mesh_index];
+        const ptgpu_material& mat = model->materials[model->meshes[xf.mesh_index].material_index];
+        const bool double_sided = mat.double_sided || mat.has_volume;  // :377-378
+        xf.cull = double_sided ? 0u : 1u;
+    }
+    std::memcpy(c->scene_min, table.scene_min, 12);
+    std::memcpy(c->scene_max, table.scene_max, 12);
+
+    // ---- shading data ----
+    std::vector<ptd::DevObject> objects(model->n_objects);
+    c->object_mesh.resize(model->n_objects);
+    for (uint32_t i = 0; i < model->n_objects; ++i) {
+        const ptgpu_object& o = model->objects[i];
+        for (int col = 0; col < 4; ++col)
+            for (int r = 0; r < 3; ++r) {
+                objects[i].model[col * 3 + r] = o.model_matrix[col * 4 + r];
+                objects[i].normal[col * 3 + r] = o.normal_matrix[col * 4 + r];
+            }
+        objects[i].mesh_index = o.mesh_index;
+        c->object_mesh[i] = o.mesh_index;
+    }
+    std::vector<ptd::DevMesh> meshes(model->n_meshes);
+    for (uint32_t i = 0; i < model->n_meshes; ++i)
+        meshes[i] = {model->meshes[i].first_vertex, model->meshes[i].first_index, model->meshes[i].material_index,
+                     model->meshes[i].n_indices};
+    static_assert(sizeof(ptd::DevMaterial) == sizeof(ptgpu_material), "material layouts must match");
+    static_assert(sizeof(ptgpu_vertex) == 48, "vertex is three float4");
+    std::vector<ptd::DevImage> images(model->n_images);
+    for (uint32_t i = 0; i < model->n_images; ++i)
+        images[i] = {model->images[i].width, model->images[i].height, static_cast<uint32_t>(model->images[i].texel_offset), 0u};
+    float lut[256];
+    for (int i = 0; i < 256; ++i) lut[i] = srgb_to_linear_host(static_cast<float>(i) / 255.0f);
+    const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // CPUTexture<hdr_pixel>::create_white_texture, cpu_framebuffer.cc:104
+    const float* env_px = white;
+    int env_w = 1, env_h = 1;
+    if (env && env->rgba) {
+        if (env->width <= 0 || env->height <= 0) return c->fail(PTGPU_E_INVALID, "environment map has a bad size");
+        env_px = env->rgba;
+        env_w = env->width;
+        env_h = env->height;
+    }
+
+    int rc;
+    if ((rc = upload(c, c->nodes, all_nodes.data(), all_nodes.size()))) return rc;
+    if ((rc = upload(c, c->tris, all_tris.data(), all_tris.size()))) return rc;
+    if ((rc = upload(c, c->instances, table.instances.data(), table.instances.size()))) return rc;
+    if ((rc = upload(c, c->xforms, table.xforms.data(), table.xforms.size()))) return rc;
+    if ((rc = upload(c, c->objects, objects.data(), objects.size()))) return rc;
+    if ((rc = upload(c, c->meshes, meshes.data(), meshes.size()))) return rc;
+    if ((rc = upload(c, c->vertices, model->vertices, static_cast<size_t>(model->n_vertices)))) return rc;
+    if ((rc = upload(c, c->indices, model->indices, static_cast<size_t>(model->n_indices)))) return rc;
+    if ((rc = upload(c, c->materials, model->materials, model->n_materials))) return rc;
+    if ((rc = upload(c, c->images, images.data(), images.size()))) return rc;
+    if ((rc = upload(c, c->texels, reinterpret_cast<const uint32_t*>(model->texels), static_cast<size_t>(model->n_texels)))) return rc;
+    if ((rc = upload(c, c->env, env_px, static_cast<size_t>(env_w) * env_h * 4))) return rc;
+    if ((rc = upload(c, c->lut, lut, 256))) return rc;
+
+    ptd::SceneDev& sc = c->scene;
+    sc.nodes = c->nodes.as<ptd::DevNode>();
+    sc.tris = c->tris.as<ptd::DevTri>();
+    sc.instances = c->instances.as<ptd::DevInstance>();
+    sc.xforms = c->xforms.as<ptd::DevXform>();
+    sc.objects = c->objects.as<ptd::DevObject>();
+    sc.meshes = c->meshes.as<ptd::DevMesh>();
+    sc.vertices = c->vertices.as<float4>();
+    sc.indices = c->indices.as<uint32_t>();
+    sc.materials = c->materials.as<ptd::DevMaterial>();
+    sc.images = c->images.as<ptd::DevImage>();
+    sc.texels = c->texels.as<uint32_t>();
+    sc.env = c->env.as<float4>();
+    sc.srgb_lut = c->lut.as<float>();
+    sc.n_instances = static_cast<uint32_t>(table.instances.size());
+    sc.env_w = env_w;
+    sc.env_h = env_h;
+    sc.env_rot = s.envmap_rotation;
+    c->scene_settings = s;
+    c->scene_loaded = true;
+    return PTGPU_OK;
+}
+
+int ptgpu_update_camera_transform_state(ptgpu_ctx* c, const float position[3], const float direction[3], const float up[3],
+                                        float yfov, float aspect, float znear, float zfar) {
+    if (!c || !position || !direction || !up) return PTGPU_E_INVALID;
+    const H3 pos{position[0], position[1], position[2]}, dir{direction[0], direction[1], direction[2]}, upv{up[0], up[1], up[2]};
+    // glm::lookAt (right-handed) with the translation column cleared (renderer.cc:30, 36-37)
+    const H3 f = hnorm(sub(add(pos, dir), pos));
+    const H3 s = hnorm(hcross(f, upv));
+    const H3 u = hcross(s, f);
+    Mat4 view{};
+    view.at(0, 0) = s.x; view.at(1, 0) = s.y; view.at(2, 0) = s.z;
+    view.at(0, 1) = u.x; view.at(1, 1) = u.y; view.at(2, 1) = u.z;
+    view.at(0, 2) = -f.x; view.at(1, 2) = -f.y; view.at(2, 2) = -f.z;
+    view.at(3, 3) = 1.0f;
+    // glm::perspectiveRH, clip depth -1..1 (renderer.cc:31-35)
+    const float asp = aspect > 0.0f ? aspect : 1.77777777777777777f;
+    const float zf = zfar > 0.0f ? zfar : 1000.f;
+    const float th = std::tan(yfov / 2.0f);
+    Mat4 proj{};
+    proj.at(0, 0) = 1.0f / (asp * th);
+    proj.at(1, 1) = 1.0f / th;
+    proj.at(2, 2) = -(zf + znear) / (zf - znear);
+    proj.at(2, 3) = -1.0f;
+    proj.at(3, 2) = -(2.0f * zf * znear) / (zf - znear);
+    const Mat4 inv = mat_inverse(mat_mul(proj, view));  // renderer.cc:38
+    std::memcpy(c->ndc2world, inv.m, 64);
+    std::memcpy(c->origin, position, 12);
+    c->camera_set = true;
+    return PTGPU_OK;
+}
+int ptgpu_set_camera_raw(ptgpu_ctx* c, const float ndc2world[16], const float origin[3]) {
+    if (!c || !ndc2world || !origin) return PTGPU_E_INVALID;
+    std::memcpy(c->ndc2world, ndc2world, 64);
+    std::memcpy(c->origin, origin, 12);
+    c->camera_set = true;
+    return PTGPU_OK;
+}
+int ptgpu_get_camera_raw(const ptgpu_ctx* c, float ndc2world[16], float origin[3]) {
+    if (!c || !c->camera_set) return PTGPU_E_STATE;
+    std::memcpy(ndc2world, c->ndc2world, 64);
+    std::memcpy(origin, c->origin, 12);
+    return PTGPU_OK;
+}
+int ptgpu_get_scene_bound(const ptgpu_ctx* c, float bmin[3], float bmax[3]) {
+    if (!c || !bmin || !bmax) return PTGPU_E_INVALID;
+    if (!c->scene_loaded) {  // Renderer::get_scene_bound without an AS returns an empty BBox (renderer.cc:128-133)
+        for (int i = 0; i < 3; ++i) {
+            bmin[i] = 3.402823466e+38f;
+            bmax[i] = -3.402823466e+38f;
+        }
+        return PTGPU_OK;
+    }
+    std::memcpy(bmin, c->scene_min, 12);
+    std::memcpy(bmax, c->scene_max, 12);
+    return PTGPU_OK;
+}
+
+static int render_to_host(ptgpu_ctx* c, int width, int height, float* out_rgba, ptgpu_stats* stats, bool counted) {
+    if (!c || !out_rgba) return PTGPU_E_INVALID;
+    if (width <= 0 || height <= 0) return c->fail(PTGPU_E_INVALID, "render_frame: bad framebuffer size %dx%d", width, height);
+    PT_HIP(c, hipSetDevice(c->device));
+    const size_t bytes = static_cast<size_t>(width) * height * 16;
+    PT_HIP(c, c->out_rgba.ensure(bytes));
+    int rc = render_core(c, width, height, c->stream, counted, stats, c->out_rgba.as<float>(), true);
+    if (rc) return rc;
+    PT_HIP(c, hipMemcpy(out_rgba, c->out_rgba.p, bytes, hipMemcpyDeviceToHost));
+    return PTGPU_OK;
+}
+int ptgpu_render_frame(ptgpu_ctx* c, int width, int height, float* out_rgba, ptgpu_stats* stats) {
+    return render_to_host(c, width, height, out_rgba, stats, false);
+}
+int ptgpu_render_counted(ptgpu_ctx* c, int width, int height, float* out_rgba, ptgpu_stats* stats) {
+    return render_to_host(c, width, height, out_rgba, stats, true);
+}
+int ptgpu_render_frame_sums(ptgpu_ctx* c, int width, int height, float* d_sum_rgba, void* stream, ptgpu_stats* stats) {
+    if (!c || !d_sum_rgba) return PTGPU_E_INVALID;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    return render_core(c, width, height, st, false, stats, d_sum_rgba, false);
+}
+int ptgpu_resolve_sums(ptgpu_ctx* c, int width, int height, float* d_sum_rgba, uint32_t total_samples, void* stream) {
+    if (!c || !d_sum_rgba || width <= 0 || height <= 0 || total_samples == 0) return PTGPU_E_INVALID;
+    PT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    ptd::launch_divide_rgba(st, d_sum_rgba, static_cast<uint64_t>(width) * height, static_cast<float>(total_samples));
+    PT_HIP(c, hipStreamSynchronize(st));
+    return PTGPU_OK;
+}
+
+int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgpu_hit* out) {
+    if (!c || !out) return PTGPU_E_INVALID;
+    if (!c->scene_loaded || !c->camera_set) return c->fail(PTGPU_E_STATE, "render_hits: scene or camera not set");
+    if (width <= 0 || height <= 0) return c->fail(PTGPU_E_INVALID, "render_hits: bad size");
+    const uint32_t spp = c->settings.samples_per_pixel ? c->settings.samples_per_pixel : 1;
+    if (sample >= spp) return c->fail(PTGPU_E_INVALID, "render_hits: sample %u >= samples per pixel %u", sample, spp);
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_work_memory(c, 0, 0);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    const FrameGeometry g = frame_geometry(c, width, height);
+    const std::vector<float> sub = subsample_table(spp);
+    PT_HIP(c, c->subs.ensure(sub.size() * 4));
+    PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
+    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
+    const uint64_t total = static_cast<uint64_t>(g.n_tiles) * 64ull;
+    const uint64_t K = c->chunk;
+    std::vector<float4> h0, ro;
+    std::vector<uint32_t> h1;
+    for (uint64_t first = 0; first < total; first += K) {
+        const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
+        PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 4, st));
+        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, c->pools[0].at(0),
+                             c->counter.as<uint32_t>());
+        PT_HIP(c, hipMemcpyAsync(c->host_counter, c->counter.p, 4, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipStreamSynchronize(st));
+        const uint32_t n = *c->host_counter;
+        if (!n) continue;
+        ptd::launch_extend(st, c->scene, c->pools[0].at(0), n, hits, c->spill.as<uint32_t>(), spill_depth,
+                           static_cast<uint32_t>(K), nullptr);
+        h0.resize(n);
+        h1.resize(n);
+        ro.resize(n);
+        PT_HIP(c, hipMemcpyAsync(h0.data(), hits.h0, n * 16ull, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipMemcpyAsync(h1.data(), hits.h1, n * 4ull, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipMemcpyAsync(ro.data(), c->pools[0].o.p, n * 16ull, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipStreamSynchronize(st));
+        std::vector<ptgpu_hit> dec(n);
+        decode_hits(c, h0, h1, n, dec.data());
+        for (uint32_t i = 0; i < n; ++i) {  // framebuffer slot (tile order) -> pixel
+            uint32_t pid;
+            std::memcpy(&pid, &ro[i].w, 4);
+            const uint32_t tile = pid >> 6, lane = pid & 63u;
+            const uint32_t x = (tile % g.cam.tiles_x) * ptd::kTile + (lane & 7u), y = (tile / g.cam.tiles_x) * ptd::kTile + (lane >> 3);
+            out[static_cast<size_t>(y) * width + x] = dec[i];
+        }
+    }
+    return PTGPU_OK;
+}
+
+int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const float* directions, const uint8_t* any_hit,
+                         ptgpu_hit* out) {
+    if (!c || (n && (!origins || !directions || !out))) return PTGPU_E_INVALID;
+    if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays: no scene loaded");
+    PT_HIP(c, hipSetDevice(c->device));
+    int rc = ensure_work_memory(c, 0, 0);
+    if (rc) return rc;
+    hipStream_t st = c->stream;
+    const uint64_t K = c->chunk;
+    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
+    DevBuf d_o, d_d, d_a;
+    PT_HIP(c, d_o.ensure(K * 12));
+    PT_HIP(c, d_d.ensure(K * 12));
+    PT_HIP(c, d_a.ensure(K));
+    std::vector<float4> h0;
+    std::vector<uint32_t> h1;
+    for (uint64_t first = 0; first < n; first += K) {
+        const uint32_t m = static_cast<uint32_t>(std::min<uint64_t>(K, n - first));
+        PT_HIP(c, hipMemcpyAsync(d_o.p, origins + 3 * first, m * 12ull, hipMemcpyHostToDevice, st));
+        PT_HIP(c, hipMemcpyAsync(d_d.p, directions + 3 * first, m * 12ull, hipMemcpyHostToDevice, st));
+        if (any_hit) PT_HIP(c, hipMemcpyAsync(d_a.p, any_hit + first, m, hipMemcpyHostToDevice, st));
+        ptd::launch_pack_rays(st, d_o.as<float>(), d_d.as<float>(), any_hit ? d_a.as<uint8_t>() : nullptr, m, c->pools[0].at(0));
+        ptd::launch_extend(st, c->scene, c->pools[0].at(0), m, hits, c->spill.as<uint32_t>(), spill_depth, static_cast<uint32_t>(K),
+                           nullptr);
+        h0.resize(m);
+        h1.resize(m);
+        PT_HIP(c, hipMemcpyAsync(h0.data(), hits.h0, m * 16ull, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipMemcpyAsync(h1.data(), hits.h1, m * 4ull, hipMemcpyDeviceToHost, st));
+        PT_HIP(c, hipStreamSynchronize(st));
+        decode_hits(c, h0, h1, m, out + first);
+    }
+    return PTGPU_OK;
+}
+
+int ptgpu_get_bvh_info(const ptgpu_ctx* c, uint32_t mesh_index, ptgpu_bvh_info* out) {
+    if (!c || !out) return PTGPU_E_INVALID;
+    if (!c->scene_loaded || mesh_index >= c->bvh_info.size()) return PTGPU_E_STATE;
+    *out = c->bvh_info[mesh_index];
+    return PTGPU_OK;
+}
+
+int ptgpu_subsample_positions(uint32_t spp, float* out_xy) {
+    if (!out_xy || spp == 0) return PTGPU_E_INVALID;
+    const std::vector<float> t = subsample_table(spp);
+    std::memcpy(out_xy, t.data(), t.size() * 4);
+    return PTGPU_OK;
+}
+
+}  // extern "C"
