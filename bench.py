@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Benchmark of the rendering hot path on MI355X.
+
+One "step" is one full frame: every (pixel, sample) of the configuration is generated, traced and
+shaded on the GPU(s), partial sums are reduced to rank 0 over RCCL when N > 1, and the mean image
+is resolved.  The scene, textures, environment map and acceleration structure are resident in HBM
+before the timed region starts.
+
+Default workload = the reference's README benchmark (README.md:31-33): full PBR, BVH, 800x600,
+300 spp, 6 bounces, environment farmland_overcast_1k.hdr — on the seeded procedural stand-in for
+example/scene.glb, which is not available.  `value` is whole-job Mrays/s (rays = intersect_ray
+calls, counted by the scheduler from its queue sizes); ms_per_step is the time to render the frame.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: (program, width, height, spp, bounces, newrays, scene, env)
+    "readme_pbr": dict(program=2, width=800, height=600, spp=300, bounces=6, newrays=0, scene="readme", env="farmland"),
+    "ao_1080p": dict(program=1, width=1920, height=1080, spp=64, bounces=1, newrays=8, scene="readme", env="white"),
+    "raycast_640": dict(program=0, width=640, height=360, spp=1, bounces=4, newrays=0, scene="readme", env="white"),
+    "stress_4k": dict(program=2, width=3840, height=2160, spp=256, bounces=8, newrays=0, scene="stress", env="white"),
+}
+
+
+def build_scene(kind: str, detail: float, stress_tris: int):
+    from pathtracer_amd import scenes
+    if kind == "stress":
+        return scenes.stress_mesh(stress_tris)
+    return scenes.readme_standin(detail=detail)
+
+
+def load_env(kind: str):
+    if kind == "white":
+        return None
+    from pathtracer_amd import image_io
+    return image_io.load_hdr(os.path.join(ROOT, "assets", "farmland_overcast_1k.hdr"))
+
+
+def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
+    """Time the CPU oracle (a port of the reference renderer, libm math) on a bounded sample of the
+    same workload: a band of image rows around the centre at reduced spp."""
+    from oracle import binding as ob
+    from pathtracer_amd import abi
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    w, h = cfg["width"], cfg["height"]
+    cam = model.cameras[0]
+
+    def scene_for(spp):
+        st = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1)
+        s = ob.OracleScene(model, env, st)
+        s.update_camera_transform_state(cam.position, cam.direction, cam.up, cam.yfov, w / h, cam.znear, cam.zfar)
+        s.set_math_mode(ob.MATH_LIBM)
+        return s
+    rows = (max(0, h // 2 - 8), min(h, h // 2 + 8))
+    probe_spp = 1 if cfg["spp"] == 1 else 2
+    s = scene_for(probe_spp)
+    _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
+    rate = st.rays / max(st.seconds, 1e-9)
+    per_spp = st.seconds / probe_spp
+    spp = int(max(probe_spp, min(cfg["spp"], seconds_target / max(per_spp, 1e-9))))
+    if spp > probe_spp:
+        st_abi = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1)
+        s.set_settings(st_abi)
+        _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
+        rate = st.rays / max(st.seconds, 1e-9)
+    s.close()
+    return {
+        "value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"rows {rows[0]}-{rows[1]} of {h} x {w} px at {spp} spp, {cfg['bounces']} bounces: "
+                  f"{st.rays} rays in {st.seconds:.2f} s (oracle/pt_oracle.cc, libm math)",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="readme_pbr", choices=sorted(CONFIGS))
+    ap.add_argument("--detail", type=float, default=1.0, help="tessellation of the stand-in scene (1.0 = ~1M triangles)")
+    ap.add_argument("--stress-tris", type=int, default=10_000_000)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--bounces", type=int, default=-1)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    cfg = dict(CONFIGS[args.config])
+    if args.spp:
+        cfg["spp"] = args.spp
+    if args.bounces >= 0:
+        cfg["bounces"] = args.bounces
+    if args.width:
+        cfg["width"] = args.width
+    if args.height:
+        cfg["height"] = args.height
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rendering path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pathtracer_amd.renderer import (AccelerationStructureType, Perspective, RayProgramMode, Renderer,
+                                         RenderSettings)
+
+    model = build_scene(cfg["scene"], args.detail, args.stress_tris)
+    env = load_env(cfg["env"])
+    w, h = cfg["width"], cfg["height"]
+    from pathtracer_amd.distributed import combine_partial_sums, subset_settings
+    settings = subset_settings(RenderSettings(cfg["spp"], cfg["bounces"], cfg["newrays"], 8, 0.0,
+                                              RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234),
+                               rank, world)
+    r = Renderer(local_rank)
+    r.set_render_settings(settings)
+    t_load = time.time()
+    r.load_scene(model, env)
+    t_load = time.time() - t_load
+    cam = model.cameras[0]
+    r.update_camera_transform_state(cam.position, cam.direction, cam.up, Perspective(cam.yfov, cam.znear, w / h, cam.zfar))
+
+    buf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        st = r.render_frame_sums(w, h, buf.data_ptr(), stream)
+        combine_partial_sums(buf, cfg["spp"], rank, world,
+                             resolve=lambda b: r.resolve_sums(w, h, b.data_ptr(), cfg["spp"], stream))
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    rays = 0
+    samples = 0
+    extend_ms = 0.0
+    shade_ms = 0.0
+    extend_launches = 0
+    for _ in range(args.steps):
+        st = step()
+        rays += st.rays
+        samples += st.camera_samples
+        extend_ms += st.extend_ms
+        shade_ms += st.shade_ms
+        extend_launches += st.extend_launches
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    tot = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    total_rays = float(tot[1])
+    total_samples = float(tot[2])
+
+    if rank == 0:
+        ms_per_step = elapsed / max(args.steps, 1) * 1e3
+        line = {
+            "metric": "Mrays/sec (whole node) + seconds to render the README scene at 300spp 6 bounces",
+            "value": round(total_rays / elapsed / 1e6, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "seconds_per_frame": round(ms_per_step / 1e3, 4),
+            "msamples_per_s": round(total_samples / elapsed / 1e6, 3),
+            "rays_per_sample": round(total_rays / max(total_samples, 1.0), 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic: seeded procedural stand-in for example/scene.glb (not available); "
+                    + ("assets/farmland_overcast_1k.hdr environment" if cfg["env"] == "farmland" else "white environment"),
+            "config": {
+                "workload": f"{args.config}: program={RayProgramMode(cfg['program']).name} BVH {w}x{h} {cfg['spp']}spp "
+                            f"{cfg['bounces']} bounces, {model.instanced_triangles()} instanced triangles, "
+                            f"{len(model.objects)} objects",
+                "parallelism": f"sample-split x{world}" + (" + RCCL reduce(sum) to rank 0" if world > 1 else ""),
+                "scene_load_s": round(t_load, 2),
+            },
+        }
+        if world == 1 and not args.no_roofline:
+            # algorithmic bytes of the extend kernel: counted on the same scene/camera at reduced spp
+            count_settings = RenderSettings(min(cfg["spp"], 8), cfg["bounces"], cfg["newrays"], 8, 0.0,
+                                            RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234)
+            r.set_render_settings(count_settings)
+            _, cst = r.render_counted(w, h)
+            r.set_render_settings(settings)
+            V = cst.nodes_visited / cst.rays
+            T = cst.triangles_tested / cst.rays
+            I = cst.instances_tested / cst.rays
+            E = cst.instances_entered / cst.rays
+            bytes_per_ray = V * 64 + T * 48 + I * 64 + E * 128 + 32 + 20
+            extend_s = extend_ms / 1e3
+            achieved = (rays * bytes_per_ray) / extend_s / 1e9
+            line["roofline"] = {
+                "kernel": "extend_kernel<false>",
+                "bound": "hbm",
+                "achieved": round(achieved, 2),
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5),
+                "traffic": None,
+                "bytes_per_ray": round(bytes_per_ray, 1),
+                "per_ray": {"nodes_64B": round(V, 3), "triangles_48B": round(T, 3), "instance_dops_64B": round(I, 3),
+                            "instances_entered_128B": round(E, 3), "ray_read_B": 32, "hit_write_B": 20},
+                "avg_launch_ms": round(extend_ms / max(extend_launches, 1), 4),
+                "launches_per_step": extend_launches // max(args.steps, 1),
+                "extend_share_of_step": round(extend_ms / (elapsed * 1e3), 4),
+                "shade_share_of_step": round(shade_ms / (elapsed * 1e3), 4),
+                "extend_mrays_per_s": round(rays / extend_s / 1e6, 2),
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, env, cfg)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
