@@ -166,6 +166,8 @@ typedef struct ptgpu_stats {
     uint64_t triangles_tested; /* idem */
     uint64_t instances_tested; /* idem */
     uint64_t instances_entered; /* idem */
+    uint64_t wave_inner_iterations; /* idem: inner-node loop iterations summed over wavefronts */
+    uint64_t wave_triangle_iterations; /* idem: triangle loop iterations summed over wavefronts */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

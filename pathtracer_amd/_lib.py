@@ -11,7 +11,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libptgpu.so")
+LIB_PATH = os.environ.get("PTGPU_LIB") or os.path.join(_HERE, "lib", "libptgpu.so")  # PTGPU_LIB: alternative build (kernel experiments)
 _lib = None
 
 

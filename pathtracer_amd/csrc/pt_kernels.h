@@ -27,6 +27,14 @@ struct HitQueue {
     uint32_t* h1;
 };
 
+// Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot);
+// a slot of PT_NO_NODE ends the list; at most kCandMax entries are stored (longer lists are continued by a rescan).
+constexpr int kCandMax = 8;
+struct CandQueue {
+    uint2* e;
+    uint32_t stride;
+};
+
 struct CameraDev {
     float ndc2world[16];  // column-major
     float origin[3];
@@ -42,6 +50,7 @@ struct FrameDev {
 
 struct TraceCounters {   // filled by the counting variant of extend
     unsigned long long nodes, tris, inst_tested, inst_entered;
+    unsigned long long wave_inner, wave_tri;  // wavefront-level loop iterations (SIMT utilisation = lane steps / 64 / these)
 };
 
 // camera samples [first, first + n): index = (sample_slot * n_tiles + tile) * 64 + lane
@@ -50,6 +59,12 @@ void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamp
                      uint32_t* out_count);
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters);
+// Workgroups that are resident at once for the persistent extend kernel (occupancy x compute units).
+uint32_t extend_persistent_grid(int device);
+// Persistent form: a fixed grid of n_blocks workgroups pulls rays from the cursor *next_ray (zeroed here).
+void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
+                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
+                              TraceCounters* counters);
 // program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples);

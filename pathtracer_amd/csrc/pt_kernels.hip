@@ -46,20 +46,30 @@ __device__ __forceinline__ void box_test(float lox, float loy, float loz, float 
     hit = (t0x <= t1x);
     dist = forward_distance(hit, t0x, t1x);
 }
-// DOP::ray_volume_intersection with the ray projections formed in place
-// (acceleration_structure.cc:192-206, 593-597; axes acceleration_structure.h:50-58)
-__device__ __forceinline__ float dop_forward_distance(const float* __restrict__ dop, f3 o, f3 d) {
+// Ray projections on the 7 DOP axes, cached per ray (acceleration_structure.cc:593-597; axes .h:50-58)
+struct DopRay {
+    float op[7], ip[7];
+};
+__device__ __forceinline__ DopRay dop_projections(f3 o, f3 d) {
     const f3 axes[7] = {f3{1.0f, 0.0f, 0.0f}, f3{0.0f, 1.0f, 0.0f}, f3{0.0f, 0.0f, 1.0f},
                         f3{kInvSqrt3, kInvSqrt3, kInvSqrt3}, f3{kInvSqrt3, kInvSqrt3, -kInvSqrt3},
                         f3{kInvSqrt3, -kInvSqrt3, kInvSqrt3}, f3{-kInvSqrt3, kInvSqrt3, kInvSqrt3}};
+    DopRay r;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        r.op[i] = dot3(o, axes[i]);
+        r.ip[i] = 1.0f / dot3(d, axes[i]);
+    }
+    return r;
+}
+// DOP::ray_volume_intersection(projections) + forward_hit_distance (acceleration_structure.cc:192-206)
+__device__ __forceinline__ float dop_forward_distance(const float* __restrict__ dop, const DopRay& pr) {
     float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
     bool hit = true;
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
-        float op = dot3(o, axes[i]);
-        float ip = 1.0f / dot3(d, axes[i]);
-        float t0 = (dop[2 * i] - op) * ip;
-        float t1 = (dop[2 * i + 1] - op) * ip;
+        float t0 = (dop[2 * i] - pr.op[i]) * pr.ip[i];
+        float t1 = (dop[2 * i + 1] - pr.op[i]) * pr.ip[i];
         if (t0 > t1) { float s = t0; t0 = t1; t1 = s; }
         tmin = (tmin < t0) ? t0 : tmin;  // std::max(t0, tmin)
         tmax = (t1 < tmax) ? t1 : tmax;  // std::min(t1, tmax)
@@ -76,7 +86,12 @@ struct LaneHit {
 
 struct TraceCount {
     uint32_t nodes, tris, inst_tested, inst_entered;
+    uint32_t wave_inner, wave_tri;  // loop iterations executed by the wavefront (counted by one lane per iteration)
 };
+__device__ __forceinline__ bool first_active_lane() {
+    const unsigned long long m = __ballot(1);
+    return (threadIdx.x & 63u) == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1);
+}
 
 // Moller-Trumbore exactly as acceleration_structure.cc:16-49; returns true when the triangle is hit
 __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 p1, f3 p2, f3 p3, bool cull, float& A, float& B, float& t,
@@ -101,6 +116,13 @@ __device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 p1, f3 p2, f3 p3, bo
 }
 
 // BVH_AS::mesh_ray_intersection (acceleration_structure.cc:635-708) for one instance.
+//
+// Every lane walks its own tree in the reference's order (nearer child first, farther child on the
+// stack).  The loop is split "while-while": all lanes of the wavefront first descend through inner
+// nodes until each of them holds a leaf (or is finished), then all leaf-holding lanes test their
+// triangles together.  Each lane's own sequence of node visits and triangle tests is unchanged; only
+// the interleaving across lanes differs, so the 8-triangle leaf loop runs once per round for the whole
+// wave instead of once per step.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot, f3 o_ws, f3 d_ws, LaneHit& best,
                                                uint32_t (*stack)[kBlock], uint32_t* __restrict__ spill,
@@ -117,34 +139,11 @@ __device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot
     bool h_hit = false, h_back = false;
 
     int sp = 0;
-    uint32_t cur = xf.root;
+    uint32_t cur = xf.root;  // PT_NO_NODE once this lane has nothing left to visit
     for (;;) {
-        if (cur & PT_LEAF_BIT) {
-            const uint32_t first = cur & ~PT_LEAF_BIT;
-            const float4* tp = reinterpret_cast<const float4*>(sc.tris + first);
-            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-            const uint32_t count = __float_as_uint(q2.z);
-            for (uint32_t k = 0;;) {
-                if (COUNT) ++cnt.tris;
-                float A, B, t;
-                bool bf;
-                bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x}, cull, A, B,
-                                       t, bf);
-                if (ok && !(t < 0.0f) && !(t >= h_t)) {
-                    h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
-                    h_tri = __float_as_uint(q2.y);
-                    if (ANY) break;
-                }
-                if (++k >= count) break;
-                tp += 3;
-                q0 = tp[0]; q1 = tp[1]; q2 = tp[2];
-            }
-            if (ANY && h_hit) break;
-            if (sp == 0) break;
-            --sp;
-            cur = (sp < kStackLds) ? stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid];
-        } else {
-            if (COUNT) ++cnt.nodes;
+        // ---- inner nodes: until this lane holds a leaf or is finished ----
+        while (cur != PT_NO_NODE && !(cur & PT_LEAF_BIT)) {
+            if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
             const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             bool hl, hr;
@@ -168,8 +167,42 @@ __device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot
                 cur = near_ref;
             } else if (take_far) {
                 cur = far_ref;
+            } else if (sp == 0) {
+                cur = PT_NO_NODE;
             } else {
-                if (sp == 0) break;
+                --sp;
+                cur = (sp < kStackLds) ? stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid];
+            }
+        }
+        if (cur == PT_NO_NODE) break;
+        // ---- leaf: test its triangles in order, the next triangle is fetched while one is tested ----
+        {
+            const float4* tp = reinterpret_cast<const float4*>(sc.tris + (cur & ~PT_LEAF_BIT));
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            const uint32_t count = __float_as_uint(q2.z);
+            for (uint32_t k = 0;;) {
+                ++k;
+                float4 r0 = q0, r1 = q1, r2 = q2;
+                if (k < count) {
+                    tp += 3;
+                    r0 = tp[0]; r1 = tp[1]; r2 = tp[2];
+                }
+                if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
+                float A, B, t;
+                bool bf;
+                const bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x}, cull,
+                                             A, B, t, bf);
+                if (ok && !(t < 0.0f) && !(t >= h_t)) {
+                    h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                    h_tri = __float_as_uint(q2.y);
+                    if (ANY) break;
+                }
+                if (k >= count) break;
+                q0 = r0; q1 = r1; q2 = r2;
+            }
+            if ((ANY && h_hit) || sp == 0) {
+                cur = PT_NO_NODE;
+            } else {
                 --sp;
                 cur = (sp < kStackLds) ? stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gid];
             }
@@ -196,12 +229,20 @@ __device__ __forceinline__ LaneHit intersect_ray(const SceneDev& sc, f3 o, f3 d,
     best.t = kInfF; best.A = 0.0f; best.B = 0.0f; best.tri = 0; best.object = 0; best.hit = false; best.backface = false;
     const uint32_t n_inst = sc.n_instances;
     const uint32_t tid = threadIdx.x;
+    // entry distance of every instance's DOP, computed once; the first kInstLds are cached in LDS
+    {
+        const DopRay pr = dop_projections(o, d);
+        for (uint32_t k = 0; k < n_inst && k < kInstLds; ++k) dist_cache[k][tid] = dop_forward_distance(sc.instances[k].dop, pr);
+    }
+    if (COUNT) cnt.inst_tested += n_inst;
+    auto entry = [&](uint32_t k) -> float {
+        if (k < kInstLds) return dist_cache[k][tid];
+        return dop_forward_distance(sc.instances[k].dop, dop_projections(o, d));  // scenes with many objects: recomputed
+    };
     if (any_hit) {
         // cheapest objects first: walk the complexity-sorted table from the back, stop at the first hit
         for (uint32_t k = n_inst; k-- > 0;) {
-            if (COUNT) ++cnt.inst_tested;
-            float dist = dop_forward_distance(sc.instances[k].dop, o, d);
-            if (dist < kInfF) {
+            if (entry(k) < kInfF) {
                 if (COUNT) ++cnt.inst_entered;
                 trace_instance<true, COUNT>(sc, k, o, d, best, stack, spill, spill_depth, spill_stride, gid, cnt);
                 if (best.hit) break;
@@ -211,19 +252,14 @@ __device__ __forceinline__ LaneHit intersect_ray(const SceneDev& sc, f3 o, f3 d,
     }
     // closest hit: visit instances in order of increasing DOP entry distance (ties: table order),
     // stop when the nearest unvisited entry is not in front of the current hit
-    for (uint32_t k = 0; k < n_inst; ++k) {
-        if (COUNT) ++cnt.inst_tested;
-        float dist = dop_forward_distance(sc.instances[k].dop, o, d);
-        if (k < kInstLds) dist_cache[k][tid] = dist;
-    }
     float last_d = -1.0f;
     uint32_t last_k = 0;
     for (;;) {
         float best_d = kInfF;
         uint32_t best_k = PT_NO_NODE;
         for (uint32_t k = 0; k < n_inst; ++k) {
-            float dist = (k < kInstLds) ? dist_cache[k][tid] : dop_forward_distance(sc.instances[k].dop, o, d);
-            bool after = (dist > last_d) || (dist == last_d && k > last_k);
+            const float dist = entry(k);
+            const bool after = (dist > last_d) || (dist == last_d && k > last_k);
             if (after && dist < best_d) { best_d = dist; best_k = k; }
         }
         if (best_k == PT_NO_NODE || !(best_d < best.t)) break;
@@ -235,8 +271,13 @@ __device__ __forceinline__ LaneHit intersect_ray(const SceneDev& sc, f3 o, f3 d,
     return best;
 }
 
+#ifdef PT_EXTEND_WAVES
+#define PT_EXTEND_BOUNDS __launch_bounds__(kBlock, PT_EXTEND_WAVES)
+#else
+#define PT_EXTEND_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+__global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                         const float4* __restrict__ ray_d, uint32_t n,
                                                         float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                         uint32_t* __restrict__ spill, uint32_t spill_depth,
@@ -244,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, const float
     __shared__ uint32_t s_stack[kStackLds][kBlock];
     __shared__ float s_dist[kInstLds][kBlock];
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
-    TraceCount cnt{0, 0, 0, 0};
+    TraceCount cnt{0, 0, 0, 0, 0, 0};
     if (gid < n) {
         const float4 ro = ray_o[gid], rd = ray_d[gid];
         const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
@@ -258,6 +299,335 @@ __global__ __launch_bounds__(kBlock) void extend_kernel(SceneDev sc, const float
         atomicAdd(&counters->tris, static_cast<unsigned long long>(cnt.tris));
         atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(cnt.inst_tested));
         atomicAdd(&counters->inst_entered, static_cast<unsigned long long>(cnt.inst_entered));
+        atomicAdd(&counters->wave_inner, static_cast<unsigned long long>(cnt.wave_inner));
+        atomicAdd(&counters->wave_tri, static_cast<unsigned long long>(cnt.wave_tri));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// extend as two kernels: tlas (candidate instances per ray) + traverse (persistent BVH walk)
+// ---------------------------------------------------------------------------------------------
+// Rays differ by an order of magnitude in traversal length (a ray that misses every DOP costs nothing,
+// a ray grazing a million-triangle mesh visits hundreds of nodes), so "one ray per lane until the whole
+// wavefront is done" leaves most lanes idle.  The work is therefore split:
+//
+//   tlas_kernel      one ray per lane, fully coherent: the 7-slab DOP test against every instance and the
+//                    visiting order of intersect_ray (closest hit: increasing entry distance, ties in table
+//                    order; any hit: table order from the back).  Writes up to kCandMax (key, slot) pairs per
+//                    ray, ended by a PT_NO_NODE slot.
+//   traverse_kernel  persistent: every lane is a small state machine and a wavefront keeps pulling rays from
+//                    a global cursor:
+//                        IDLE   no ray                      -> refill: claim the next ray
+//                        NEXT   ray needs its next instance -> accept the hit of the finished one, read the
+//                                                              next candidate, enter it or write the result
+//                        INNER  current reference is a node -> one node step
+//                        LEAF   current reference is a leaf -> one triangle test
+//                    Per iteration the wavefront runs the phase that most lanes wait for, so its instructions
+//                    are shared.  A lane's own sequence of instance visits, node visits and triangle tests is
+//                    exactly that of the simple kernel above; only the interleaving across lanes changes.
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 8
+#endif
+#ifndef PT_NEXT_MIN
+#define PT_NEXT_MIN 8
+#endif
+#ifndef PT_BURST
+#define PT_BURST 4
+#endif
+#ifndef PT_RAY_BLOCK
+#define PT_RAY_BLOCK 128u
+#endif
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                      const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                                      TraceCounters* counters) {
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    const float4 ro = ray_o[gid], rd = ray_d[gid];
+    const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
+    const DopRay pr = dop_projections(ld3(ro), ld3(rd));
+    float key[kCandMax];
+    uint32_t slot[kCandMax];
+#pragma unroll
+    for (int j = 0; j < kCandMax; ++j) { key[j] = kInfF; slot[j] = PT_NO_NODE; }
+    const uint32_t n_inst = sc.n_instances;
+    for (uint32_t k = 0; k < n_inst; ++k) {
+        const float dist = dop_forward_distance(sc.instances[k].dop, pr);
+        if (dist < kInfF) {
+            // sorted insertion; strict '<' keeps table order among equal distances
+            float ck = any_hit ? -static_cast<float>(k) : dist;
+            uint32_t cs = k;
+#pragma unroll
+            for (int j = 0; j < kCandMax; ++j) {
+                const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
+                const float tk = key[j];
+                const uint32_t ts = slot[j];
+                key[j] = sw ? ck : tk;
+                slot[j] = sw ? cs : ts;
+                ck = sw ? tk : ck;
+                cs = sw ? ts : cs;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kCandMax; ++j)
+        if (j == 0 || slot[j - 1] != PT_NO_NODE)
+            cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j]);
+    if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
+}
+
+// Continuation of the visiting order for rays that consumed kCandMax candidates: rescan all DOPs.
+__device__ __noinline__ uint2 tlas_rescan(const SceneDev& sc, f3 ow, f3 dw, bool any_hit, float last_key, uint32_t last_slot) {
+    const DopRay pr = dop_projections(ow, dw);
+    uint32_t next = PT_NO_NODE;
+    float best_d = kInfF;
+    if (any_hit) {
+        for (uint32_t k = last_slot; k-- > 0;)
+            if (dop_forward_distance(sc.instances[k].dop, pr) < kInfF) { next = k; best_d = 0.0f; break; }
+    } else {
+        for (uint32_t k = 0; k < sc.n_instances; ++k) {
+            const float dist = dop_forward_distance(sc.instances[k].dop, pr);
+            const bool after = (dist > last_key) || (dist == last_key && k > last_slot);
+            if (after && dist < best_d) { best_d = dist; next = k; }
+        }
+    }
+    return make_uint2(__float_as_uint(best_d), next);
+}
+
+// BBox::ray_volume_intersection + forward_hit_distance for lanes whose inverse direction is finite: no
+// operand can be NaN then, so hardware min/max/min3/max3 return what the reference's compare-and-select
+// forms return (up to the sign of a zero, which no later comparison observes).
+__device__ __forceinline__ float box_entry_fast(float lox, float loy, float loz, float hix, float hiy, float hiz, f3 o, f3 inv) {
+    const float ax = (lox - o.x) * inv.x, ay = (loy - o.y) * inv.y, az = (loz - o.z) * inv.z;
+    const float bx = (hix - o.x) * inv.x, by = (hiy - o.y) * inv.y, bz = (hiz - o.z) * inv.z;
+    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
+}
+
+enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u };
+
+template <bool COUNT>
+__global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                 const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                                 float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                                 uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
+                                                 uint32_t* __restrict__ next_ray, TraceCounters* counters) {
+    __shared__ uint32_t s_stack[kStackLds][kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t gthread = blockIdx.x * kBlock + tid;  // owner of one spill column
+    TraceCount cnt{0, 0, 0, 0, 0, 0};
+
+    // ---- per-lane state ----
+    uint32_t rid = PT_NO_NODE;   // ray index, PT_NO_NODE = idle
+    uint32_t cursor = 0;         // next candidate to read
+    uint32_t flags = 0;          // F_*
+    float b_t = kInfF;           // world distance of the best accepted hit (its record is already in hit0/hit1)
+    uint32_t slot = PT_NO_NODE;  // instance being traversed
+    f3 o = mk3(0.0f), d = mk3(0.0f), inv = mk3(0.0f);
+    float h_t = kInfF, h_A = 0.0f, h_B = 0.0f;
+    uint32_t h_tri = 0;
+    bool h_hit = false, h_back = false;
+    int sp = 0;
+    uint32_t cur = PT_NO_NODE;   // reference to visit next; PT_NO_NODE = instance finished / none entered
+    uint32_t leaf_rem = 0;       // triangles left in the current leaf, 0 = leaf not started
+    bool exhausted = false;      // wave-uniform: the global cursor has passed n
+    uint32_t local_next = 0, local_end = 0;  // wave-uniform: block of rays owned by this wavefront
+
+    auto pop = [&]() {
+        if (sp == 0) {
+            cur = PT_NO_NODE;
+        } else {
+            --sp;
+            cur = (sp < kStackLds) ? s_stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread];
+        }
+    };
+
+    for (;;) {
+        // ---- census of lane states (wave-uniform scalars) ----
+        const bool alive = (rid != PT_NO_NODE);
+        const bool st_next = alive && (cur == PT_NO_NODE);
+        const bool st_inner = alive && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT);
+        const bool st_leaf = alive && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT);
+        const unsigned long long m_idle = __ballot(!alive);
+        const uint32_t n_idle = __popcll(m_idle);
+        const uint32_t n_next = __popcll(__ballot(st_next));
+        const uint32_t n_inner = __popcll(__ballot(st_inner));
+        const uint32_t n_leaf = __popcll(__ballot(st_leaf));
+
+        if (!exhausted && n_idle >= PT_REFILL_MIN) {
+            // ================= refill: hand rays to the idle lanes =================
+            // The wavefront owns a block of PT_RAY_BLOCK consecutive rays claimed with ONE atomic on the global
+            // cursor (a single word sustains well under 100 M atomics/s, far less than the ray rate).
+            if (local_next >= local_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next_ray, static_cast<uint32_t>(PT_RAY_BLOCK));
+                base = __builtin_amdgcn_readfirstlane(base);
+                local_next = base;
+                local_end = (base < n) ? ((n - base < PT_RAY_BLOCK) ? n : base + PT_RAY_BLOCK) : base;
+                if (base >= n) exhausted = true;
+            }
+            const uint32_t avail = local_end - local_next;
+            const uint32_t rank = __popcll(m_idle & lt_mask);
+            if (!alive && rank < avail) {
+                rid = local_next + rank;
+                cursor = 0;
+                flags = 0;
+                b_t = kInfF;
+                slot = PT_NO_NODE;
+                cur = PT_NO_NODE;
+                h_hit = false;
+                leaf_rem = 0;
+            }
+            local_next += (n_idle < avail) ? n_idle : avail;
+        } else if (n_next && (n_next >= PT_NEXT_MIN || (n_inner + n_leaf) == 0u)) {
+            // ================= next instance: accept the finished one's hit, enter the next candidate =================
+            if (st_next) {
+                const float4 ro = ray_o[rid], rd = ray_d[rid];
+                const f3 ow = ld3(ro), dw = ld3(rd);
+                if (slot == PT_NO_NODE) {
+                    if ((__float_as_uint(rd.w) >> 8) & 1u) flags |= F_ANY;
+                } else if (h_hit) {
+                    // back to a world-space distance and acceptance (acceleration_structure.cc:704-706, 616-623)
+                    const DevXform& xf = sc.xforms[slot];
+                    const f3 p = o + d * h_t;
+                    const f3 p_ws = xform(xf.model, p, 1.0f);
+                    const float t_ws = length3(p_ws - ow);
+                    if ((t_ws > 0.0f) && (t_ws < b_t)) {
+                        b_t = t_ws;
+                        flags |= F_BHIT;
+                        hit0[rid] = make_float4(t_ws, h_A, h_B, __uint_as_float(h_tri));
+                        hit1[rid] = xf.object_index | (h_back ? 0x40000000u : 0u) | 0x80000000u;
+                    }
+                }
+                const bool any_hit = (flags & F_ANY) != 0;
+                uint32_t next_slot = PT_NO_NODE;
+                if (!(any_hit && (flags & F_BHIT))) {
+                    uint2 e;
+                    if (cursor < kCandMax) {
+                        e = cand.e[static_cast<size_t>(cursor) * cand.stride + rid];
+                    } else {  // more than kCandMax candidate instances along this ray: continue by rescanning
+                        const uint2 last = cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid];
+                        e = tlas_rescan(sc, ow, dw, any_hit, __uint_as_float(last.x), last.y);
+                        if (e.y != PT_NO_NODE) cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid] = e;
+                    }
+                    ++cursor;
+                    if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) next_slot = e.y;
+                }
+                if (next_slot == PT_NO_NODE) {
+                    if (!(flags & F_BHIT)) {
+                        hit0[rid] = make_float4(kInfF, 0.0f, 0.0f, 0.0f);
+                        hit1[rid] = 0u;
+                    }
+                    rid = PT_NO_NODE;
+                    slot = PT_NO_NODE;
+                } else {
+                    if (COUNT) ++cnt.inst_entered;
+                    slot = next_slot;
+                    const DevXform& xf = sc.xforms[slot];
+                    o = xform(xf.inv, ow, 1.0f);
+                    d = normalize3(xform(xf.inv, dw, 0.0f));
+                    inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                    flags &= ~(F_CULL | F_SLOW);
+                    if (xf.cull) flags |= F_CULL;
+                    const bool finite = (fabsf(inv.x) < kInfF) && (fabsf(inv.y) < kInfF) && (fabsf(inv.z) < kInfF);
+                    if (!finite) flags |= F_SLOW;
+                    h_t = kInfF; h_A = 0.0f; h_B = 0.0f; h_tri = 0; h_hit = false; h_back = false;
+                    sp = 0;
+                    cur = xf.root;
+                    leaf_rem = 0;
+                }
+            }
+        } else if (n_inner && n_inner >= n_leaf) {
+            // ================= inner-node steps for the lanes that hold a node =================
+            for (int burst = 0;;) {
+                const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT);
+                if (act) {
+                    if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
+                    const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    float dl = box_entry_fast(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv);
+                    float dr = box_entry_fast(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv);
+                    if (flags & F_SLOW) {  // an infinite inverse direction can produce NaNs: exact select forms
+                        bool hl, hr;
+                        box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, hl, dl);
+                        box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, hr, dr);
+                    }
+                    const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
+                    // a child is visited when its box is hit in front and nearer than the current hit; the
+                    // reference pushes the farther child first and pops the nearer one next — the nearer child
+                    // stays in a register here instead of a push followed by a pop
+                    const bool take_l = h_t > dl, take_r = h_t > dr;
+                    const bool l_first = dl < dr;
+                    const uint32_t near_ref = l_first ? left : right, far_ref = l_first ? right : left;
+                    const bool take_near = l_first ? take_l : take_r, take_far = l_first ? take_r : take_l;
+                    if (take_near) {
+                        if (take_far) {
+                            if (sp < kStackLds) s_stack[sp][tid] = far_ref;
+                            else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
+                                spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = far_ref;
+                            ++sp;
+                        }
+                        cur = near_ref;
+                    } else if (take_far) {
+                        cur = far_ref;
+                    } else {
+                        pop();
+                    }
+                }
+                if (++burst >= PT_BURST) break;
+                const uint32_t still = __popcll(__ballot((rid != PT_NO_NODE) && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT)));
+                if (still * 2u < n_inner) break;
+            }
+        } else if (n_leaf) {
+            // ================= triangle tests for the lanes that hold a leaf =================
+            for (int burst = 0;;) {
+                const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT);
+                if (act) {
+                    if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
+                    const uint32_t idx = cur & ~PT_LEAF_BIT;
+                    const float4* tp = reinterpret_cast<const float4*>(sc.tris + idx);
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    uint32_t rem = leaf_rem ? leaf_rem : __float_as_uint(q2.z);
+                    float A, B, t;
+                    bool bf;
+                    const bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x},
+                                                 (flags & F_CULL) != 0, A, B, t, bf);
+                    bool stop = false;
+                    if (ok && !(t < 0.0f) && !(t >= h_t)) {
+                        h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                        h_tri = __float_as_uint(q2.y);
+                        stop = (flags & F_ANY) != 0;  // any-hit traversal ends at the first accepted triangle
+                    }
+                    --rem;
+                    if (stop) {
+                        cur = PT_NO_NODE;
+                        leaf_rem = 0;
+                    } else if (rem) {
+                        cur = PT_LEAF_BIT | (idx + 1u);
+                        leaf_rem = rem;
+                    } else {
+                        leaf_rem = 0;
+                        pop();
+                    }
+                }
+                if (++burst >= PT_BURST) break;
+                const uint32_t still = __popcll(__ballot((rid != PT_NO_NODE) && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT)));
+                if (still * 2u < n_leaf) break;
+            }
+        } else {
+            break;  // no live lane: either the cursor is exhausted or (unreachable) all 64 lanes just refilled nothing
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters->nodes, static_cast<unsigned long long>(cnt.nodes));
+        atomicAdd(&counters->tris, static_cast<unsigned long long>(cnt.tris));
+        atomicAdd(&counters->inst_entered, static_cast<unsigned long long>(cnt.inst_entered));
+        atomicAdd(&counters->wave_inner, static_cast<unsigned long long>(cnt.wave_inner));
+        atomicAdd(&counters->wave_tri, static_cast<unsigned long long>(cnt.wave_tri));
     }
 }
 
@@ -833,6 +1203,30 @@ void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n
     else
         hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
                            hits.h1, spill, spill_depth, spill_stride, counters);
+}
+uint32_t extend_persistent_grid(int device) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
+        per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
+    return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(cus);
+}
+void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
+                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
+                              TraceCounters* counters) {
+    if (!n) return;
+    const uint32_t grid = std::min<uint32_t>(n_blocks, blocks_for(n));
+    const uint32_t stride = n_blocks * kBlock;  // one spill column per persistent thread
+    (void)hipMemsetAsync(next_ray, 0, sizeof(uint32_t), st);
+    if (counters) {
+        hipLaunchKernelGGL(tlas_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        hipLaunchKernelGGL(traverse_kernel<true>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
+                           hits.h1, spill, spill_depth, stride, next_ray, counters);
+    } else {
+        hipLaunchKernelGGL(tlas_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        hipLaunchKernelGGL(traverse_kernel<false>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
+                           hits.h1, spill, spill_depth, stride, next_ray, counters);
+    }
 }
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples) {

@@ -110,11 +110,6 @@ struct DevBuf {
     T* as() const { return static_cast<T*>(p); }
 };
 
-struct Segment {
-    int pool;
-    uint64_t offset;
-    uint32_t count;
-};
 struct Pool {
     DevBuf o, d, p;
     uint64_t cap = 0, top = 0;
@@ -144,9 +139,11 @@ struct ptgpu_ctx {
     float origin[3];
 
     // work memory
-    uint32_t chunk = 1u << 21;
+    uint32_t chunk = 1u << 22;     // rays per launch and camera samples per batch (PTGPU_CHUNK)
     Pool pools[2];
-    DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba;
+    DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand;
+    bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
+    uint32_t persist_blocks = 0;   // resident workgroups of the persistent extend kernel
     uint32_t* host_counter = nullptr;  // pinned
     hipEvent_t ev[6] = {};
 
@@ -244,10 +241,28 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces) {
     PT_HIP(c, c->hit0.ensure(K * 16));
     PT_HIP(c, c->hit1.ensure(K * 4));
     const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
-    PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * K * 4 + 16));
+    if (c->persistent && !c->persist_blocks) {
+        c->persist_blocks = ptd::extend_persistent_grid(c->device);
+        if (const char* b = std::getenv("PTGPU_PERSIST_BLOCKS")) c->persist_blocks = static_cast<uint32_t>(std::max(1, std::atoi(b)));
+        if (std::getenv("PTGPU_VERBOSE")) std::fprintf(stderr, "[ptgpu] persistent extend grid: %u workgroups\n", c->persist_blocks);
+    }
+    const uint64_t spill_columns = c->persistent ? static_cast<uint64_t>(c->persist_blocks) * ptd::kBlock : K;
+    PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * spill_columns * 4 + 16));
+    PT_HIP(c, c->ray_cursor.ensure(16));
+    if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * K * sizeof(uint2)));
     PT_HIP(c, c->counter.ensure(16));
     PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
     return PTGPU_OK;
+}
+
+void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t n, const ptd::HitQueue& hits,
+                ptd::TraceCounters* tc) {
+    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    if (c->persistent)
+        ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->chunk},
+                                      c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(), tc);
+    else
+        ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->chunk, tc);
 }
 
 struct RenderOut {
@@ -288,7 +303,6 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     if (counted) PT_HIP(c, hipMemsetAsync(d_tc, 0, sizeof(ptd::TraceCounters), st));
 
     ptd::SceneDev sc = c->scene;
-    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     uint32_t* d_count = c->counter.as<uint32_t>();
 
@@ -296,7 +310,17 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
     const uint64_t K = c->chunk;
     PT_HIP(c, hipEventRecord(c->ev[4], st));
-    std::vector<Segment> stack;
+    // Generation-ordered schedule.  A frame says "drain pool `pool` down to floor_in, spawned rays go on top of
+    // the other pool (which holds older rays up to floor_out)".  A generation is consumed from the top of its pool
+    // in launches of up to `chunk` rays; when it is gone the spawned generation is drained the same way, pools
+    // swapped.  If the other pool cannot take a launch's worst-case output, the rays spawned so far are drained
+    // first (depth first), so live rays stay bounded whatever the branching factor is.
+    struct Frame {
+        int pool;
+        uint64_t floor_in, floor_out;
+    };
+    constexpr uint64_t kMinLaunch = 1u << 16;
+    std::vector<Frame> frames;
     float ms = 0.0f;
     for (uint64_t first = 0; first < total; first += K) {
         const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
@@ -314,29 +338,34 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.camera_samples += n_cam;
         if (!n_cam) continue;
         c->pools[0].top = n_cam;
-        stack.push_back({0, 0, n_cam});
+        frames.assign(1, Frame{0, 0, 0});
 
-        while (!stack.empty()) {
-            Segment seg = stack.back();
-            stack.pop_back();
-            Pool& in = c->pools[seg.pool];
-            Pool& op = c->pools[seg.pool ^ 1];
-            uint32_t n = seg.count;
+        while (!frames.empty()) {
+            const Frame f = frames.back();
+            Pool& in = c->pools[f.pool];
+            Pool& op = c->pools[f.pool ^ 1];
+            if (in.top <= f.floor_in) {  // generation consumed: drain what it spawned
+                frames.pop_back();
+                if (op.top > f.floor_out) frames.push_back({f.pool ^ 1, f.floor_out, f.floor_in});
+                continue;
+            }
+            uint64_t n64 = std::min<uint64_t>(K, in.top - f.floor_in);
             if (fanout) {
                 const uint64_t room = (op.cap - op.top) / fanout;
-                if (room < std::min<uint64_t>(n, 64))
-                    return c->fail(PTGPU_E_NOMEM, "ray pool exhausted (%llu rays live); lower the chunk size",
-                                   static_cast<unsigned long long>(op.top));
-                if (room < n) {  // shade only the newest rays of the segment now, the rest later
-                    const uint32_t m = static_cast<uint32_t>(room);
-                    stack.push_back({seg.pool, seg.offset, n - m});
-                    seg.offset += n - m;
-                    n = m;
+                if (room < std::min<uint64_t>(n64, kMinLaunch)) {
+                    if (op.top <= f.floor_out)
+                        return c->fail(PTGPU_E_NOMEM, "ray pool exhausted (%llu rays live); lower the chunk size",
+                                       static_cast<unsigned long long>(in.top + op.top));
+                    frames.push_back({f.pool ^ 1, f.floor_out, in.top});  // depth first: drain the spawned rays, then resume
+                    continue;
                 }
+                n64 = std::min(n64, room);
             }
-            const ptd::RayQueue rq = in.at(seg.offset);
+            const uint32_t n = static_cast<uint32_t>(n64);
+            const uint64_t offset = in.top - n;
+            const ptd::RayQueue rq = in.at(offset);
             PT_HIP(c, hipEventRecord(c->ev[0], st));
-            ptd::launch_extend(st, sc, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, static_cast<uint32_t>(K), d_tc);
+            run_extend(c, st, rq, n, hits, d_tc);
             PT_HIP(c, hipEventRecord(c->ev[1], st));
             if (fanout) PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
             PT_HIP(c, hipEventRecord(c->ev[2], st));
@@ -351,13 +380,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             out.rays += n;
             ++out.extend_launches;
             ++out.shade_launches;
-            in.top = seg.offset;  // the popped rays were the newest of their pool
-            if (fanout) {
-                const uint32_t n_out = *c->host_counter;
-                for (uint64_t o = 0; o < n_out; o += K)
-                    stack.push_back({seg.pool ^ 1, op.top + o, static_cast<uint32_t>(std::min<uint64_t>(K, n_out - o))});
-                op.top += n_out;
-            }
+            in.top = offset;  // the launched rays were the newest of their pool
+            if (fanout) op.top += *c->host_counter;
         }
     }
     if (d_rgba) {
@@ -375,6 +399,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.triangles_tested = tc.tris;
         out.instances_tested = tc.inst_tested;
         out.instances_entered = tc.inst_entered;
+        out.wave_inner_iterations = tc.wave_inner;
+        out.wave_triangle_iterations = tc.wave_tri;
     }
     if (stats) *stats = out;
     return PTGPU_OK;
@@ -444,6 +470,7 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
     d.accel_struct_type = PTGPU_AS_BVH;
     d.sample_step = 1;
     ctx->settings = d;
+    if (const char* m = std::getenv("PTGPU_EXTEND")) ctx->persistent = std::strcmp(m, "simple") != 0;
     if (const char* k = std::getenv("PTGPU_CHUNK")) {
         long v = std::atol(k);
         if (v >= 1024) ctx->chunk = static_cast<uint32_t>(std::min<long>(v, 1l << 26)) & ~63u;
@@ -718,7 +745,6 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     const std::vector<float> sub = subsample_table(spp);
     PT_HIP(c, c->subs.ensure(sub.size() * 4));
     PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
-    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     const uint64_t total = static_cast<uint64_t>(g.n_tiles) * 64ull;
     const uint64_t K = c->chunk;
@@ -733,8 +759,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
         PT_HIP(c, hipStreamSynchronize(st));
         const uint32_t n = *c->host_counter;
         if (!n) continue;
-        ptd::launch_extend(st, c->scene, c->pools[0].at(0), n, hits, c->spill.as<uint32_t>(), spill_depth,
-                           static_cast<uint32_t>(K), nullptr);
+        run_extend(c, st, c->pools[0].at(0), n, hits, nullptr);
         h0.resize(n);
         h1.resize(n);
         ro.resize(n);
@@ -764,7 +789,6 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
     if (rc) return rc;
     hipStream_t st = c->stream;
     const uint64_t K = c->chunk;
-    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     DevBuf d_o, d_d, d_a;
     PT_HIP(c, d_o.ensure(K * 12));
@@ -778,8 +802,7 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
         PT_HIP(c, hipMemcpyAsync(d_d.p, directions + 3 * first, m * 12ull, hipMemcpyHostToDevice, st));
         if (any_hit) PT_HIP(c, hipMemcpyAsync(d_a.p, any_hit + first, m, hipMemcpyHostToDevice, st));
         ptd::launch_pack_rays(st, d_o.as<float>(), d_d.as<float>(), any_hit ? d_a.as<uint8_t>() : nullptr, m, c->pools[0].at(0));
-        ptd::launch_extend(st, c->scene, c->pools[0].at(0), m, hits, c->spill.as<uint32_t>(), spill_depth, static_cast<uint32_t>(K),
-                           nullptr);
+        run_extend(c, st, c->pools[0].at(0), m, hits, nullptr);
         h0.resize(m);
         h1.resize(m);
         PT_HIP(c, hipMemcpyAsync(h0.data(), hits.h0, m * 16ull, hipMemcpyDeviceToHost, st));
