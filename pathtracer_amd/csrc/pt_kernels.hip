@@ -329,10 +329,15 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #define PT_REFILL_MIN 8
 #endif
 #ifndef PT_NEXT_MIN
-#define PT_NEXT_MIN 8
+#define PT_NEXT_MIN 16
 #endif
 #ifndef PT_BURST
-#define PT_BURST 4
+#define PT_BURST 8
+#endif
+#ifdef PT_NO_UNROLL
+#define PT_BURST_UNROLL _Pragma("unroll 1")
+#else
+#define PT_BURST_UNROLL
 #endif
 #ifndef PT_RAY_BLOCK
 #define PT_RAY_BLOCK 128u
@@ -543,6 +548,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             }
         } else if (n_inner && n_inner >= n_leaf) {
             // ================= inner-node steps for the lanes that hold a node =================
+            PT_BURST_UNROLL
             for (int burst = 0;;) {
                 const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT);
                 if (act) {
@@ -584,6 +590,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             }
         } else if (n_leaf) {
             // ================= triangle tests for the lanes that hold a leaf =================
+            PT_BURST_UNROLL
             for (int burst = 0;;) {
                 const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT);
                 if (act) {
@@ -1003,7 +1010,12 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 // ---------------------------------------------------------------------------------------------
 // shade: PBR (ray_program.cc:234-391)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
+#ifdef PT_SHADE_WAVES
+#define PT_SHADE_BOUNDS __launch_bounds__(kBlock, PT_SHADE_WAVES)
+#else
+#define PT_SHADE_BOUNDS __launch_bounds__(kBlock)
+#endif
+__global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
