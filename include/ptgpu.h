@@ -158,7 +158,7 @@ typedef struct ptgpu_stats {
     uint64_t camera_samples; /* (pixel, sample) pairs generated */
     uint64_t extend_launches;
     uint64_t shade_launches;
-    double extend_ms;  /* sum of HIP-event durations of the extend kernel launches */
+    double extend_ms;  /* sum of HIP-event durations of the extend stage (instance pass + traversal) */
     double shade_ms;   /* same for the shade kernels */
     double generate_ms;
     double total_ms;   /* HIP-event time from first to last kernel of the call */
@@ -168,6 +168,7 @@ typedef struct ptgpu_stats {
     uint64_t instances_entered; /* idem */
     uint64_t wave_inner_iterations; /* idem: inner-node loop iterations summed over wavefronts */
     uint64_t wave_triangle_iterations; /* idem: triangle loop iterations summed over wavefronts */
+    double traverse_ms; /* part of extend_ms spent in the traversal kernel (0 with PTGPU_EXTEND=simple) */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

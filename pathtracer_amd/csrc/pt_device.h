@@ -2,9 +2,11 @@
 //
 // Layout (all arrays live in HBM, addressed through SceneDev):
 //   nodes      64 B   binary BVH node holding BOTH children's boxes and references, so one inner-node
-//                     visit is one 64-byte fetch (4 x dwordx4); half of a 128-byte L2 line.
-//   tris       48 B   p1 p2 p3 + index of the triangle's first entry in the mesh index list + size of
-//                     the leaf (valid in a leaf's first triangle) — 3 x dwordx4.
+//                     visit is one 64-byte fetch (4 x dwordx4); half of a 128-byte L2 line.  The planes are
+//                     grouped per axis (left lo, left hi, right lo, right hi) so that the slab arithmetic
+//                     runs on register pairs.
+//   tris       48 B   p1, p2 - p1, p3 - p1 + index of the triangle's first entry in the mesh index list +
+//                     size of the leaf (valid in a leaf's first triangle) — 3 x dwordx4.
 //   instances  64 B   world-space 14-DOP (7 min/max pairs) + object and mesh index.
 //   xforms    128 B   inverse model and model matrices (3 rows used) + root reference + cull flag.
 //   vertices   48 B   position normal tangent uv — 3 x dwordx4.
@@ -17,6 +19,7 @@
 
 #define PT_LEAF_BIT 0x80000000u
 #define PT_NO_NODE 0xffffffffu
+#define PT_IDLE 0xfffffffeu      // traversal lane without a ray (never a valid reference)
 
 namespace ptd {
 
@@ -30,6 +33,18 @@ struct alignas(16) DevTri {       // 48 B
     float p1[3], p2[3], p3[3];
     uint32_t index;               // triangleIndex of the reference: 3 * triangle number in the mesh
     uint32_t leaf_count;          // number of triangles of the leaf that starts here
+    uint32_t pad;
+};
+// Traversal forms of the two records above, made once at scene load.
+struct alignas(16) NodeQ {        // 64 B
+    float x[4], y[4], z[4];       // per axis: left lo, left hi, right lo, right hi
+    uint32_t left, right;
+    uint32_t pad0, pad1;
+};
+struct alignas(16) TriQ {         // 48 B
+    float p1[3], e1[3], e2[3];    // e1 = p2 - p1, e2 = p3 - p1 (the first two operations of the triangle test)
+    uint32_t index;
+    uint32_t leaf_count;          // triangles of the leaf from this one on (1 = last of its leaf)
     uint32_t pad;
 };
 struct alignas(16) DevInstance {  // 64 B
@@ -74,8 +89,8 @@ struct DevImage {                 // 16 B
 };
 
 struct SceneDev {
-    const DevNode* nodes;
-    const DevTri* tris;
+    const NodeQ* nodes;
+    const TriQ* tris;
     const DevInstance* instances;
     const DevXform* xforms;
     const DevObject* objects;

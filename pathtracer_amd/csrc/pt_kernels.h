@@ -51,6 +51,9 @@ struct FrameDev {
 struct TraceCounters {   // filled by the counting variant of extend
     unsigned long long nodes, tris, inst_tested, inst_entered;
     unsigned long long wave_inner, wave_tri;  // wavefront-level loop iterations (SIMT utilisation = lane steps / 64 / these)
+    // scheduler census of the persistent kernel: [phase 0 refill, 1 next, 2 inner, 3 leaf][0 executions, 1 steps,
+    // 2..5 lanes idle / waiting for next / holding a node / holding a leaf, summed over the steps]
+    unsigned long long census[4][6];
 };
 
 // camera samples [first, first + n): index = (sample_slot * n_tiles + tile) * 64 + lane
@@ -62,9 +65,10 @@ void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n
 // Workgroups that are resident at once for the persistent extend kernel (occupancy x compute units).
 uint32_t extend_persistent_grid(int device);
 // Persistent form: a fixed grid of n_blocks workgroups pulls rays from the cursor *next_ray (zeroed here).
+// `between`, when given, is recorded after the instance pass and before the traversal kernel.
 void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
                               uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
-                              TraceCounters* counters);
+                              TraceCounters* counters, hipEvent_t between = nullptr);
 // program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples);

@@ -87,6 +87,7 @@ struct LaneHit {
 struct TraceCount {
     uint32_t nodes, tris, inst_tested, inst_entered;
     uint32_t wave_inner, wave_tri;  // loop iterations executed by the wavefront (counted by one lane per iteration)
+    uint32_t census[4][6];
 };
 __device__ __forceinline__ bool first_active_lane() {
     const unsigned long long m = __ballot(1);
@@ -94,9 +95,9 @@ __device__ __forceinline__ bool first_active_lane() {
 }
 
 // Moller-Trumbore exactly as acceleration_structure.cc:16-49; returns true when the triangle is hit
-__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 p1, f3 p2, f3 p3, bool cull, float& A, float& B, float& t,
+// (e1 = p2 - p1 and e2 = p3 - p1 come precomputed with the triangle)
+__device__ __forceinline__ bool ray_triangle(f3 o, f3 d, f3 p1, f3 e1, f3 e2, bool cull, float& A, float& B, float& t,
                                              bool& backface) {
-    f3 e1 = p2 - p1, e2 = p3 - p1;
     f3 pv = cross3(d, e2);
     float det = dot3(e1, pv);
     if (det == 0.0f) return false;
@@ -148,8 +149,8 @@ __device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             bool hl, hr;
             float dl, dr;
-            box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, hl, dl);
-            box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, hr, dr);
+            box_test(n0.x, n1.x, n2.x, n0.y, n1.y, n2.y, o, inv, hl, dl);
+            box_test(n0.z, n1.z, n2.z, n0.w, n1.w, n2.w, o, inv, hr, dr);
             const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
             const bool take_l = hl && (h_t > dl), take_r = hr && (h_t > dr);
             // the reference pushes the farther child first and pops the nearer one next; the nearer
@@ -424,10 +425,13 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     const uint32_t lane = tid & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t gthread = blockIdx.x * kBlock + tid;  // owner of one spill column
-    TraceCount cnt{0, 0, 0, 0, 0, 0};
+    TraceCount cnt{};
 
     // ---- per-lane state ----
-    uint32_t rid = PT_NO_NODE;   // ray index, PT_NO_NODE = idle
+    // `cur` doubles as the lane's state: PT_IDLE = no ray, PT_NO_NODE = the ray needs its next instance,
+    // bit 31 clear = node to visit, bit 31 set (below PT_IDLE) = triangle to test next.
+    uint32_t cur = PT_IDLE;
+    uint32_t rid = 0;            // ray index
     uint32_t cursor = 0;         // next candidate to read
     uint32_t flags = 0;          // F_*
     float b_t = kInfF;           // world distance of the best accepted hit (its record is already in hit0/hit1)
@@ -437,36 +441,46 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     uint32_t h_tri = 0;
     bool h_hit = false, h_back = false;
     int sp = 0;
-    uint32_t cur = PT_NO_NODE;   // reference to visit next; PT_NO_NODE = instance finished / none entered
-    uint32_t leaf_rem = 0;       // triangles left in the current leaf, 0 = leaf not started
     bool exhausted = false;      // wave-uniform: the global cursor has passed n
     uint32_t local_next = 0, local_end = 0;  // wave-uniform: block of rays owned by this wavefront
 
-    auto pop = [&]() {
-        if (sp == 0) {
-            cur = PT_NO_NODE;
-        } else {
-            --sp;
-            cur = (sp < kStackLds) ? s_stack[sp][tid] : spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread];
-        }
+    auto is_node = [](uint32_t c) { return static_cast<int32_t>(c) >= 0; };
+    auto is_leaf = [](uint32_t c) { return static_cast<int32_t>(c) < -2; };
+    // The top of the stack is read when a step starts, together with the node or triangle, so that a pop costs
+    // no second round trip; only the rare entry beyond the LDS part is fetched when it is needed.
+    auto peek = [&]() -> uint32_t {
+        const int at = (sp > kStackLds) ? kStackLds - 1 : sp - 1;
+        return (sp > 0) ? s_stack[at][tid] : PT_NO_NODE;
+    };
+    auto pop_to = [&](uint32_t top) {
+        if (sp > kStackLds) top = spill[static_cast<size_t>(sp - 1 - kStackLds) * spill_stride + gthread];
+        cur = top;
+        sp = (sp > 0) ? sp - 1 : 0;
     };
 
     for (;;) {
         // ---- census of lane states (wave-uniform scalars) ----
-        const bool alive = (rid != PT_NO_NODE);
-        const bool st_next = alive && (cur == PT_NO_NODE);
-        const bool st_inner = alive && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT);
-        const bool st_leaf = alive && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT);
-        const unsigned long long m_idle = __ballot(!alive);
+        const unsigned long long m_idle = __ballot(cur == PT_IDLE);
         const uint32_t n_idle = __popcll(m_idle);
-        const uint32_t n_next = __popcll(__ballot(st_next));
-        const uint32_t n_inner = __popcll(__ballot(st_inner));
-        const uint32_t n_leaf = __popcll(__ballot(st_leaf));
+        const uint32_t n_next = __popcll(__ballot(cur == PT_NO_NODE));
+        const uint32_t n_inner = __popcll(__ballot(is_node(cur)));
+        const uint32_t n_leaf = 64u - n_idle - n_next - n_inner;
 
+        auto tally = [&](int phase, int steps) {
+            if (lane == 0) {
+                cnt.census[phase][0] += 1;
+                cnt.census[phase][1] += steps;
+                cnt.census[phase][2] += n_idle * steps;
+                cnt.census[phase][3] += n_next * steps;
+                cnt.census[phase][4] += n_inner * steps;
+                cnt.census[phase][5] += n_leaf * steps;
+            }
+        };
         if (!exhausted && n_idle >= PT_REFILL_MIN) {
             // ================= refill: hand rays to the idle lanes =================
             // The wavefront owns a block of PT_RAY_BLOCK consecutive rays claimed with ONE atomic on the global
             // cursor (a single word sustains well under 100 M atomics/s, far less than the ray rate).
+            if (COUNT) tally(0, 1);
             if (local_next >= local_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(next_ray, static_cast<uint32_t>(PT_RAY_BLOCK));
@@ -477,7 +491,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             }
             const uint32_t avail = local_end - local_next;
             const uint32_t rank = __popcll(m_idle & lt_mask);
-            if (!alive && rank < avail) {
+            if (cur == PT_IDLE && rank < avail) {
                 rid = local_next + rank;
                 cursor = 0;
                 flags = 0;
@@ -485,12 +499,12 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                 slot = PT_NO_NODE;
                 cur = PT_NO_NODE;
                 h_hit = false;
-                leaf_rem = 0;
             }
             local_next += (n_idle < avail) ? n_idle : avail;
         } else if (n_next && (n_next >= PT_NEXT_MIN || (n_inner + n_leaf) == 0u)) {
             // ================= next instance: accept the finished one's hit, enter the next candidate =================
-            if (st_next) {
+            if (COUNT) tally(1, 1);
+            if (cur == PT_NO_NODE) {
                 const float4 ro = ray_o[rid], rd = ray_d[rid];
                 const f3 ow = ld3(ro), dw = ld3(rd);
                 if (slot == PT_NO_NODE) {
@@ -527,7 +541,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                         hit0[rid] = make_float4(kInfF, 0.0f, 0.0f, 0.0f);
                         hit1[rid] = 0u;
                     }
-                    rid = PT_NO_NODE;
+                    cur = PT_IDLE;
                     slot = PT_NO_NODE;
                 } else {
                     if (COUNT) ++cnt.inst_entered;
@@ -543,62 +557,57 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     h_t = kInfF; h_A = 0.0f; h_B = 0.0f; h_tri = 0; h_hit = false; h_back = false;
                     sp = 0;
                     cur = xf.root;
-                    leaf_rem = 0;
                 }
             }
         } else if (n_inner && n_inner >= n_leaf) {
             // ================= inner-node steps for the lanes that hold a node =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
-                const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT);
-                if (act) {
+                if (is_node(cur)) {
                     if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
                     const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
-                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                    float dl = box_entry_fast(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv);
-                    float dr = box_entry_fast(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv);
+                    const float4 nx = np[0], ny = np[1], nz = np[2], nr = np[3];
+                    const uint32_t top = peek();
+                    float dl = box_entry_fast(nx.x, ny.x, nz.x, nx.y, ny.y, nz.y, o, inv);
+                    float dr = box_entry_fast(nx.z, ny.z, nz.z, nx.w, ny.w, nz.w, o, inv);
                     if (flags & F_SLOW) {  // an infinite inverse direction can produce NaNs: exact select forms
                         bool hl, hr;
-                        box_test(n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, o, inv, hl, dl);
-                        box_test(n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, o, inv, hr, dr);
+                        box_test(nx.x, ny.x, nz.x, nx.y, ny.y, nz.y, o, inv, hl, dl);
+                        box_test(nx.z, ny.z, nz.z, nx.w, ny.w, nz.w, o, inv, hr, dr);
                     }
-                    const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
-                    // a child is visited when its box is hit in front and nearer than the current hit; the
-                    // reference pushes the farther child first and pops the nearer one next — the nearer child
-                    // stays in a register here instead of a push followed by a pop
-                    const bool take_l = h_t > dl, take_r = h_t > dr;
+                    const uint32_t left = __float_as_uint(nr.x), right = __float_as_uint(nr.y);
+                    // A child is visited when its box is hit in front and nearer than the current hit (a missed box
+                    // has distance +inf); the reference pushes the farther child first and pops the nearer one next
+                    // — the nearer child stays in a register here.  The distances are never NaN, so the farther
+                    // child can only be taken when the nearer one is.
                     const bool l_first = dl < dr;
                     const uint32_t near_ref = l_first ? left : right, far_ref = l_first ? right : left;
-                    const bool take_near = l_first ? take_l : take_r, take_far = l_first ? take_r : take_l;
-                    if (take_near) {
-                        if (take_far) {
-                            if (sp < kStackLds) s_stack[sp][tid] = far_ref;
-                            else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
-                                spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = far_ref;
-                            ++sp;
-                        }
+                    const float d_near = l_first ? dl : dr, d_far = l_first ? dr : dl;
+                    if (h_t > d_far) {
+                        if (sp < kStackLds) s_stack[sp][tid] = far_ref;
+                        else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
+                            spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = far_ref;
+                        ++sp;
                         cur = near_ref;
-                    } else if (take_far) {
-                        cur = far_ref;
+                    } else if (h_t > d_near) {
+                        cur = near_ref;
                     } else {
-                        pop();
+                        pop_to(top);
                     }
                 }
-                if (++burst >= PT_BURST) break;
-                const uint32_t still = __popcll(__ballot((rid != PT_NO_NODE) && (cur != PT_NO_NODE) && !(cur & PT_LEAF_BIT)));
-                if (still * 2u < n_inner) break;
+                if (++burst >= PT_BURST) { if (COUNT) tally(2, burst); break; }
+                const uint32_t still = __popcll(__ballot(is_node(cur)));
+                if (still * 2u < n_inner) { if (COUNT) tally(2, burst); break; }
             }
         } else if (n_leaf) {
             // ================= triangle tests for the lanes that hold a leaf =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
-                const bool act = (rid != PT_NO_NODE) && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT);
-                if (act) {
+                if (is_leaf(cur)) {
                     if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
-                    const uint32_t idx = cur & ~PT_LEAF_BIT;
-                    const float4* tp = reinterpret_cast<const float4*>(sc.tris + idx);
+                    const float4* tp = reinterpret_cast<const float4*>(sc.tris + (cur & ~PT_LEAF_BIT));
                     const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                    uint32_t rem = leaf_rem ? leaf_rem : __float_as_uint(q2.z);
+                    const uint32_t top = peek();
                     float A, B, t;
                     bool bf;
                     const bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x},
@@ -609,21 +618,17 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                         h_tri = __float_as_uint(q2.y);
                         stop = (flags & F_ANY) != 0;  // any-hit traversal ends at the first accepted triangle
                     }
-                    --rem;
                     if (stop) {
                         cur = PT_NO_NODE;
-                        leaf_rem = 0;
-                    } else if (rem) {
-                        cur = PT_LEAF_BIT | (idx + 1u);
-                        leaf_rem = rem;
+                    } else if (__float_as_uint(q2.z) != 1u) {  // triangles of this leaf left, this one included
+                        cur = cur + 1u;
                     } else {
-                        leaf_rem = 0;
-                        pop();
+                        pop_to(top);
                     }
                 }
-                if (++burst >= PT_BURST) break;
-                const uint32_t still = __popcll(__ballot((rid != PT_NO_NODE) && (cur != PT_NO_NODE) && (cur & PT_LEAF_BIT)));
-                if (still * 2u < n_leaf) break;
+                if (++burst >= PT_BURST) { if (COUNT) tally(3, burst); break; }
+                const uint32_t still = __popcll(__ballot(is_leaf(cur)));
+                if (still * 2u < n_leaf) { if (COUNT) tally(3, burst); break; }
             }
         } else {
             break;  // no live lane: either the cursor is exhausted or (unreachable) all 64 lanes just refilled nothing
@@ -635,6 +640,9 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
         atomicAdd(&counters->inst_entered, static_cast<unsigned long long>(cnt.inst_entered));
         atomicAdd(&counters->wave_inner, static_cast<unsigned long long>(cnt.wave_inner));
         atomicAdd(&counters->wave_tri, static_cast<unsigned long long>(cnt.wave_tri));
+        if (lane == 0)
+            for (int ph = 0; ph < 4; ++ph)
+                for (int k = 0; k < 6; ++k) atomicAdd(&counters->census[ph][k], static_cast<unsigned long long>(cnt.census[ph][k]));
     }
 }
 
@@ -1225,17 +1233,19 @@ uint32_t extend_persistent_grid(int device) {
 }
 void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
                               uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
-                              TraceCounters* counters) {
+                              TraceCounters* counters, hipEvent_t between) {
     if (!n) return;
     const uint32_t grid = std::min<uint32_t>(n_blocks, blocks_for(n));
     const uint32_t stride = n_blocks * kBlock;  // one spill column per persistent thread
     (void)hipMemsetAsync(next_ray, 0, sizeof(uint32_t), st);
     if (counters) {
         hipLaunchKernelGGL(tlas_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (between) (void)hipEventRecord(between, st);
         hipLaunchKernelGGL(traverse_kernel<true>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
                            hits.h1, spill, spill_depth, stride, next_ray, counters);
     } else {
         hipLaunchKernelGGL(tlas_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (between) (void)hipEventRecord(between, st);
         hipLaunchKernelGGL(traverse_kernel<false>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
                            hits.h1, spill, spill_depth, stride, next_ray, counters);
     }

@@ -145,7 +145,7 @@ struct ptgpu_ctx {
     bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
     uint32_t persist_blocks = 0;   // resident workgroups of the persistent extend kernel
     uint32_t* host_counter = nullptr;  // pinned
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[7] = {};
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -256,11 +256,12 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces) {
 }
 
 void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t n, const ptd::HitQueue& hits,
-                ptd::TraceCounters* tc) {
+                ptd::TraceCounters* tc, hipEvent_t between = nullptr) {
     const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     if (c->persistent)
         ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->chunk},
-                                      c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(), tc);
+                                      c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(), tc,
+                                      between);
     else
         ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->chunk, tc);
 }
@@ -320,6 +321,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         uint64_t floor_in, floor_out;
     };
     constexpr uint64_t kMinLaunch = 1u << 16;
+    const char* dump_path = std::getenv("PTGPU_DUMP_RAYS");
+    const uint64_t dump_launch = std::getenv("PTGPU_DUMP_LAUNCH") ? std::strtoull(std::getenv("PTGPU_DUMP_LAUNCH"), nullptr, 10) : 0;
     std::vector<Frame> frames;
     float ms = 0.0f;
     for (uint64_t first = 0; first < total; first += K) {
@@ -364,8 +367,17 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             const uint32_t n = static_cast<uint32_t>(n64);
             const uint64_t offset = in.top - n;
             const ptd::RayQueue rq = in.at(offset);
+            if (dump_path && out.extend_launches == dump_launch) {  // developer aid: one launch's rays as raw float4 o[n], d[n]
+                std::vector<float4> buf(2ull * n);
+                PT_HIP(c, hipMemcpy(buf.data(), rq.o, n * 16ull, hipMemcpyDeviceToHost));
+                PT_HIP(c, hipMemcpy(buf.data() + n, rq.d, n * 16ull, hipMemcpyDeviceToHost));
+                if (FILE* f = std::fopen(dump_path, "wb")) {
+                    std::fwrite(buf.data(), 16, buf.size(), f);
+                    std::fclose(f);
+                }
+            }
             PT_HIP(c, hipEventRecord(c->ev[0], st));
-            run_extend(c, st, rq, n, hits, d_tc);
+            run_extend(c, st, rq, n, hits, d_tc, c->ev[6]);
             PT_HIP(c, hipEventRecord(c->ev[1], st));
             if (fanout) PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
             PT_HIP(c, hipEventRecord(c->ev[2], st));
@@ -375,6 +387,10 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             PT_HIP(c, hipStreamSynchronize(st));
             PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
             out.extend_ms += ms;
+            if (c->persistent) {
+                PT_HIP(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[1]));
+                out.traverse_ms += ms;
+            }
             PT_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
             out.shade_ms += ms;
             out.rays += n;
@@ -401,6 +417,15 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.instances_entered = tc.inst_entered;
         out.wave_inner_iterations = tc.wave_inner;
         out.wave_triangle_iterations = tc.wave_tri;
+        if (std::getenv("PTGPU_VERBOSE")) {
+            static const char* names[4] = {"refill", "next", "inner", "leaf"};
+            for (int ph = 0; ph < 4; ++ph) {
+                const double steps = static_cast<double>(std::max<unsigned long long>(tc.census[ph][1], 1));
+                std::fprintf(stderr, "[ptgpu] census %-6s executions %llu steps %llu mean lanes: idle %.1f next %.1f node %.1f leaf %.1f\n",
+                             names[ph], tc.census[ph][0], tc.census[ph][1], tc.census[ph][2] / steps, tc.census[ph][3] / steps,
+                             tc.census[ph][4] / steps, tc.census[ph][5] / steps);
+            }
+        }
     }
     if (stats) *stats = out;
     return PTGPU_OK;
@@ -554,7 +579,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         const ptgpu_mesh& m = model->meshes[i];
         pth::MeshTree tree;
         pth::build_mesh_tree(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf, naive, tree);
-        if (all_tris.size() + tree.tris.size() >= (1ull << 31) || all_nodes.size() + tree.nodes.size() >= (1ull << 31))
+        if (all_tris.size() + tree.tris.size() >= (1ull << 31) - 2 || all_nodes.size() + tree.nodes.size() >= (1ull << 31))
             return c->fail(PTGPU_E_INVALID, "scene exceeds 2^31 triangles or nodes");
         pth::relocate(tree, static_cast<uint32_t>(all_nodes.size()), static_cast<uint32_t>(all_tris.size()));
         mesh_root[i] = tree.root;
@@ -606,9 +631,40 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         env_h = env->height;
     }
 
+    // traversal forms: planes grouped per axis, triangle edges precomputed (binary32 subtraction, as the test does)
+    std::vector<ptd::NodeQ> q_nodes(all_nodes.size());
+    for (size_t i = 0; i < all_nodes.size(); ++i) {
+        const ptd::DevNode& n = all_nodes[i];
+        ptd::NodeQ& q = q_nodes[i];
+        float* axes[3] = {q.x, q.y, q.z};
+        for (int a = 0; a < 3; ++a) {
+            axes[a][0] = n.l_lo[a];
+            axes[a][1] = n.l_hi[a];
+            axes[a][2] = n.r_lo[a];
+            axes[a][3] = n.r_hi[a];
+        }
+        q.left = n.left;
+        q.right = n.right;
+        q.pad0 = q.pad1 = 0;
+    }
+    std::vector<ptd::TriQ> q_tris(all_tris.size());
+    uint32_t in_leaf = 0;  // the builder marks a leaf's first triangle with the leaf size; every triangle gets the rest count
+    for (size_t i = 0; i < all_tris.size(); ++i) {
+        const ptd::DevTri& t = all_tris[i];
+        ptd::TriQ& q = q_tris[i];
+        for (int a = 0; a < 3; ++a) {
+            q.p1[a] = t.p1[a];
+            q.e1[a] = t.p2[a] - t.p1[a];
+            q.e2[a] = t.p3[a] - t.p1[a];
+        }
+        q.index = t.index;
+        if (t.leaf_count) in_leaf = t.leaf_count;
+        q.leaf_count = in_leaf ? in_leaf-- : 1u;
+        q.pad = 0;
+    }
     int rc;
-    if ((rc = upload(c, c->nodes, all_nodes.data(), all_nodes.size()))) return rc;
-    if ((rc = upload(c, c->tris, all_tris.data(), all_tris.size()))) return rc;
+    if ((rc = upload(c, c->nodes, q_nodes.data(), q_nodes.size()))) return rc;
+    if ((rc = upload(c, c->tris, q_tris.data(), q_tris.size()))) return rc;
     if ((rc = upload(c, c->instances, table.instances.data(), table.instances.size()))) return rc;
     if ((rc = upload(c, c->xforms, table.xforms.data(), table.xforms.size()))) return rc;
     if ((rc = upload(c, c->objects, objects.data(), objects.size()))) return rc;
@@ -622,8 +678,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     if ((rc = upload(c, c->lut, lut, 256))) return rc;
 
     ptd::SceneDev& sc = c->scene;
-    sc.nodes = c->nodes.as<ptd::DevNode>();
-    sc.tris = c->tris.as<ptd::DevTri>();
+    sc.nodes = c->nodes.as<ptd::NodeQ>();
+    sc.tris = c->tris.as<ptd::TriQ>();
     sc.instances = c->instances.as<ptd::DevInstance>();
     sc.xforms = c->xforms.as<ptd::DevXform>();
     sc.objects = c->objects.as<ptd::DevObject>();

@@ -1,0 +1,35 @@
+"""Summarise one tools/profile_bench.sh output directory: per-kernel time from the kernel trace statistics and
+HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled: gfx950 tallies the 128-byte
+read requests at 64 bytes each; both counters are in kilobytes)."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+root = sys.argv[1]
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel(?:<\w+>)?)", name)
+    return m.group(1) if m else name[:40]
+
+
+print("== kernel trace statistics ==")
+for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        print(f"{short(r['Name']):32s} calls {int(r['Calls']):7d} total_ms {float(r['TotalDurationNs'])/1e6:10.2f} "
+              f"avg_us {float(r['AverageNs'])/1e3:9.1f} pct {float(r['Percentage']):6.2f}")
+
+for tag, scale in (("fetch", 2.0), ("write", 1.0)):
+    acc = collections.defaultdict(float)
+    cnt = collections.defaultdict(int)
+    for f in glob.glob(root + f"/{tag}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            acc[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    print(f"== {tag} pass (KB -> bytes, x{scale:g}) ==")
+    for (k, c), v in sorted(acc.items()):
+        print(f"{k:32s} {c:12s} dispatches {cnt[(k, c)]:7d} total_GB {v*1024*scale/1e9:10.3f} "
+              f"per_launch_MB {v*1024*scale/cnt[(k, c)]/1e6:10.3f}")
