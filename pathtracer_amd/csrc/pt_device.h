@@ -3,7 +3,7 @@
 // Layout (all arrays live in HBM, addressed through SceneDev):
 //   nodes      64 B   binary BVH node holding BOTH children's boxes and references, so one inner-node
 //                     visit is one 64-byte fetch (4 x dwordx4); half of a 128-byte L2 line.  The planes are
-//                     grouped per axis (left lo, left hi, right lo, right hi) so that the slab arithmetic
+//                     grouped per axis (left lo, right lo, left hi, right hi) so that the slab arithmetic
 //                     runs on register pairs.
 //   tris       48 B   p1, p2 - p1, p3 - p1 + index of the triangle's first entry in the mesh index list +
 //                     size of the leaf (valid in a leaf's first triangle) — 3 x dwordx4.
@@ -37,7 +37,7 @@ struct alignas(16) DevTri {       // 48 B
 };
 // Traversal forms of the two records above, made once at scene load.
 struct alignas(16) NodeQ {        // 64 B
-    float x[4], y[4], z[4];       // per axis: left lo, left hi, right lo, right hi
+    float x[4], y[4], z[4];       // per axis: left lo, right lo, left hi, right hi
     uint32_t left, right;
     uint32_t pad0, pad1;
 };

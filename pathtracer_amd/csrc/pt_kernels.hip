@@ -149,8 +149,8 @@ __device__ __forceinline__ void trace_instance(const SceneDev& sc, uint32_t slot
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             bool hl, hr;
             float dl, dr;
-            box_test(n0.x, n1.x, n2.x, n0.y, n1.y, n2.y, o, inv, hl, dl);
-            box_test(n0.z, n1.z, n2.z, n0.w, n1.w, n2.w, o, inv, hr, dr);
+            box_test(n0.x, n1.x, n2.x, n0.z, n1.z, n2.z, o, inv, hl, dl);
+            box_test(n0.y, n1.y, n2.y, n0.w, n1.w, n2.w, o, inv, hr, dr);
             const uint32_t left = __float_as_uint(n3.x), right = __float_as_uint(n3.y);
             const bool take_l = hl && (h_t > dl), take_r = hr && (h_t > dr);
             // the reference pushes the farther child first and pops the nearer one next; the nearer
@@ -568,12 +568,12 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     const float4* np = reinterpret_cast<const float4*>(sc.nodes + cur);
                     const float4 nx = np[0], ny = np[1], nz = np[2], nr = np[3];
                     const uint32_t top = peek();
-                    float dl = box_entry_fast(nx.x, ny.x, nz.x, nx.y, ny.y, nz.y, o, inv);
-                    float dr = box_entry_fast(nx.z, ny.z, nz.z, nx.w, ny.w, nz.w, o, inv);
+                    float dl = box_entry_fast(nx.x, ny.x, nz.x, nx.z, ny.z, nz.z, o, inv);
+                    float dr = box_entry_fast(nx.y, ny.y, nz.y, nx.w, ny.w, nz.w, o, inv);
                     if (flags & F_SLOW) {  // an infinite inverse direction can produce NaNs: exact select forms
                         bool hl, hr;
-                        box_test(nx.x, ny.x, nz.x, nx.y, ny.y, nz.y, o, inv, hl, dl);
-                        box_test(nx.z, ny.z, nz.z, nx.w, ny.w, nz.w, o, inv, hr, dr);
+                        box_test(nx.x, ny.x, nz.x, nx.z, ny.z, nz.z, o, inv, hl, dl);
+                        box_test(nx.y, ny.y, nz.y, nx.w, ny.w, nz.w, o, inv, hr, dr);
                     }
                     const uint32_t left = __float_as_uint(nr.x), right = __float_as_uint(nr.y);
                     // A child is visited when its box is hit in front and nearer than the current hit (a missed box

@@ -639,8 +639,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         float* axes[3] = {q.x, q.y, q.z};
         for (int a = 0; a < 3; ++a) {
             axes[a][0] = n.l_lo[a];
-            axes[a][1] = n.l_hi[a];
-            axes[a][2] = n.r_lo[a];
+            axes[a][1] = n.r_lo[a];
+            axes[a][2] = n.l_hi[a];
             axes[a][3] = n.r_hi[a];
         }
         q.left = n.left;
