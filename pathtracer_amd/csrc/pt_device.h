@@ -9,7 +9,10 @@
 //                     size of the leaf (valid in a leaf's first triangle) — 3 x dwordx4.
 //   instances  64 B   world-space 14-DOP (7 min/max pairs) + object and mesh index.
 //   xforms    128 B   inverse model and model matrices (3 rows used) + root reference + cull flag.
-//   vertices   48 B   position normal tangent uv — 3 x dwordx4.
+//   corners   144 B   per triangle (mesh order, not BVH order) its three vertices de-indexed:
+//                     position normal tangent uv, 3 x dwordx4 each.
+//   objects   256 B   model and normal matrices, first corner record of the mesh, material with its
+//                     texture descriptors.
 // Arithmetic follows the reference operation by operation (one binary32 rounding each; the build
 // disables contraction), so hit records can be compared bit for bit with a CPU evaluation.
 #pragma once
@@ -61,31 +64,29 @@ struct alignas(16) DevXform {     // 128 B
     uint32_t mesh_index;
     uint32_t pad[4];
 };
-struct alignas(16) DevObject {    // shading-time object data, 112 B
+struct DevTexture {               // 12 B; width 0 = the material has no such texture
+    int32_t width, height;
+    uint32_t offset;              // first texel in SceneDev::texels
+};
+struct alignas(16) DevMaterial {  // shading form of ptgpu_material, its texture descriptors inline; 144 B
+    float base_color[4];
+    float emissive[3], emissive_strength;
+    float attenuation[3], metallic;
+    float roughness, ior, f0, transmission;
+    float alpha_cutoff;
+    uint32_t double_sided, has_volume, alpha_blending;
+    DevTexture base_color_tex, mr_tex, normal_tex, transmission_tex, emissive_tex;
+    uint32_t pad;
+};
+// Everything shading needs to know about an instance in ONE record (256 B), so that a hit costs three
+// dependent fetches — hit record -> object -> triangle corners -> texels — instead of walking
+// object -> mesh -> index list -> vertices -> material -> image table.
+struct alignas(16) DevObject {
     float model[12];              // columns c0..c3 xyz
     float normal[12];             // NormalMatrix columns c0..c3 xyz
-    uint32_t mesh_index;
+    uint32_t tri_base;            // first record of the object's mesh in SceneDev::corners
     uint32_t pad[3];
-};
-struct DevMesh {                  // 16 B
-    uint32_t first_vertex, first_index, material, n_indices;
-};
-struct DevMaterial {              // mirrors ptgpu_material, 100 B
-    float base_color[4];
-    float emissive[3];
-    float attenuation[3];
-    float metallic, roughness;
-    int32_t base_color_tex, mr_tex, normal_tex;
-    float ior, f0, transmission;
-    int32_t transmission_tex, emissive_tex;
-    float emissive_strength;
-    int32_t double_sided, has_volume, alpha_blending;
-    float alpha_cutoff;
-};
-struct DevImage {                 // 16 B
-    int32_t width, height;
-    uint32_t offset;              // in texels
-    uint32_t pad;
+    DevMaterial mat;
 };
 
 struct SceneDev {
@@ -94,11 +95,7 @@ struct SceneDev {
     const DevInstance* instances;
     const DevXform* xforms;
     const DevObject* objects;
-    const DevMesh* meshes;
-    const float4* vertices;       // 3 float4 per vertex
-    const uint32_t* indices;
-    const DevMaterial* materials;
-    const DevImage* images;
+    const float4* corners;        // per triangle in mesh order: its three vertices, 3 float4 each (144 B)
     const uint32_t* texels;       // RGBA8
     const float4* env;
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)

@@ -724,14 +724,21 @@ __device__ __forceinline__ Taps bilinear_taps(float u, float v, int w, int h) {
     t.y1 = wrap_coord(y0 + 1, h);
     return t;
 }
+// The sRGB decode table (256 floats) is copied to LDS by every shading workgroup: a texture sample decodes twelve
+// channels, and as global gathers those would be half of the kernel's vector memory instructions.
+__shared__ float s_srgb_lut[256];
+__device__ __forceinline__ void stage_srgb_lut(const SceneDev& sc) {
+    static_assert(kBlock == 256, "one table entry per thread");
+    s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    __syncthreads();
+}
 __device__ __forceinline__ float4 texel8(const SceneDev& sc, uint32_t word, bool srgb) {
     uint32_t r = word & 0xffu, g = (word >> 8) & 0xffu, b = (word >> 16) & 0xffu, a = word >> 24;
     float fa = static_cast<float>(a) / 255.0f;
-    if (srgb) return make_float4(sc.srgb_lut[r], sc.srgb_lut[g], sc.srgb_lut[b], fa);
+    if (srgb) return make_float4(s_srgb_lut[r], s_srgb_lut[g], s_srgb_lut[b], fa);
     return make_float4(static_cast<float>(r) / 255.0f, static_cast<float>(g) / 255.0f, static_cast<float>(b) / 255.0f, fa);
 }
-__device__ __forceinline__ float4 sample_image(const SceneDev& sc, int image, float u, float v, bool srgb) {
-    const DevImage im = sc.images[image];
+__device__ __forceinline__ float4 sample_image(const SceneDev& sc, const DevTexture& im, float u, float v, bool srgb) {
     const Taps t = bilinear_taps(u, v, im.width, im.height);
     const uint32_t* px = sc.texels + im.offset;
     const uint32_t w00 = px[t.y0 * im.width + t.x0], w10 = px[t.y0 * im.width + t.x1], w01 = px[t.y1 * im.width + t.x0],
@@ -743,26 +750,26 @@ __device__ __forceinline__ float4 sample_image(const SceneDev& sc, int image, fl
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 sample_albedo(const SceneDev& sc, const DevMaterial& m, float u, float v) {
     float4 f = make_float4(m.base_color[0], m.base_color[1], m.base_color[2], m.base_color[3]);
-    if (m.base_color_tex >= 0) f = mul4(f, sample_image(sc, m.base_color_tex, u, v, true));
+    if (m.base_color_tex.width) f = mul4(f, sample_image(sc, m.base_color_tex, u, v, true));
     return f;
 }
 __device__ __forceinline__ float4 sample_orm(const SceneDev& sc, const DevMaterial& m, float u, float v) {
     float4 f = make_float4(1.0f, m.roughness, m.metallic, 1.0f);
-    if (m.mr_tex >= 0) f = mul4(f, sample_image(sc, m.mr_tex, u, v, false));
+    if (m.mr_tex.width) f = mul4(f, sample_image(sc, m.mr_tex, u, v, false));
     return f;
 }
 __device__ __forceinline__ float4 sample_normals(const SceneDev& sc, const DevMaterial& m, float u, float v) {
-    if (m.normal_tex >= 0) return sample_image(sc, m.normal_tex, u, v, false);
+    if (m.normal_tex.width) return sample_image(sc, m.normal_tex, u, v, false);
     return make_float4(0.5f, 0.5f, 1.0f, 0.0f);
 }
 __device__ __forceinline__ f3 sample_emissive(const SceneDev& sc, const DevMaterial& m, float u, float v) {
     float4 f = make_float4(m.emissive[0], m.emissive[1], m.emissive[2], 1.0f);
-    if (m.emissive_tex >= 0) f = mul4(f, sample_image(sc, m.emissive_tex, u, v, true));
+    if (m.emissive_tex.width) f = mul4(f, sample_image(sc, m.emissive_tex, u, v, true));
     return f3{f.x * m.emissive_strength, f.y * m.emissive_strength, f.z * m.emissive_strength};
 }
 __device__ __forceinline__ float sample_transmission(const SceneDev& sc, const DevMaterial& m, float u, float v) {
     float f = m.transmission;
-    if (m.transmission_tex >= 0) f *= sample_image(sc, m.transmission_tex, u, v, false).x;
+    if (m.transmission_tex.width) f *= sample_image(sc, m.transmission_tex, u, v, false).x;
     return f;
 }
 __device__ __forceinline__ f3 sample_environment(const SceneDev& sc, f3 dir) {  // brdf.cc:62-69
@@ -785,8 +792,7 @@ struct VertexD {
     float4 tangent;
     float u, v;
 };
-__device__ __forceinline__ VertexD load_vertex(const SceneDev& sc, uint32_t idx) {
-    const float4* p = sc.vertices + static_cast<size_t>(idx) * 3;
+__device__ __forceinline__ VertexD load_vertex(const float4* __restrict__ p) {
     const float4 a = p[0], b = p[1], c = p[2];
     VertexD r;
     r.position = f3{a.x, a.y, a.z};
@@ -850,18 +856,14 @@ struct ShadePoint {
     VertexD p;           // interpolated vertex; normal/tangent in world space after to_world()
     f3 p1, p2, p3;       // object-space corner positions (geometric normal)
     f3 bitangent;
-    uint32_t material;
     const DevObject* obj;
 };
 // get_vertex_data + interpolate_vertex_data + convert_normals_to_world_space (ray_program.cc:75-101)
 __device__ __forceinline__ ShadePoint fetch_point(const SceneDev& sc, uint32_t object, uint32_t tri, float A, float B) {
     ShadePoint sp;
     sp.obj = sc.objects + object;
-    const DevMesh mesh = sc.meshes[sp.obj->mesh_index];
-    const uint32_t* ix = sc.indices + mesh.first_index + tri;
-    const VertexD v1 = load_vertex(sc, mesh.first_vertex + ix[0]);
-    const VertexD v2 = load_vertex(sc, mesh.first_vertex + ix[1]);
-    const VertexD v3 = load_vertex(sc, mesh.first_vertex + ix[2]);
+    const float4* rec = sc.corners + static_cast<size_t>(sp.obj->tri_base + tri / 3u) * 9u;  // tri = 3 * triangle number
+    const VertexD v1 = load_vertex(rec), v2 = load_vertex(rec + 3), v3 = load_vertex(rec + 6);
     const float C = 1.0f - A - B;
     sp.p.position = lin3(v1.position, v2.position, v3.position, A, B, C);
     sp.p.normal = lin3(v1.normal, v2.normal, v3.normal, A, B, C);
@@ -872,7 +874,6 @@ __device__ __forceinline__ ShadePoint fetch_point(const SceneDev& sc, uint32_t o
     sp.p.u = lin3(v1.u, v2.u, v3.u, A, B, C);
     sp.p.v = lin3(v1.v, v2.v, v3.v, A, B, C);
     sp.p1 = v1.position; sp.p2 = v2.position; sp.p3 = v3.position;
-    sp.material = mesh.material;
     return sp;
 }
 __device__ __forceinline__ void normals_to_world(ShadePoint& sp) {
@@ -883,8 +884,30 @@ __device__ __forceinline__ void normals_to_world(ShadePoint& sp) {
     sp.bitangent = cross3(sp.p.normal, t) * sign;
 }
 
-// wavefront-level append of up to NSLOT rays per lane: slot-major order inside a wave keeps rays of
-// one lobe contiguous; one atomic per wave
+// Reserves `wave_total` consecutive queue slots for the calling wavefront with ONE atomic per workgroup: a single
+// counter word sustains well under 100 M atomics/s, which one atomic per wavefront would exceed at the
+// kernel's ray rate.  Every thread of the workgroup must call it.
+__device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t* out_count) {
+    __shared__ uint32_t s_tot[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) s_tot[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += s_tot[w];
+        s_base = t ? atomicAdd(out_count, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+        if (static_cast<uint32_t>(w) < wave) base += s_tot[w];
+    return base;
+}
+
+// append of up to NSLOT rays per lane: slot-major order inside a wave keeps rays of one lobe contiguous
 template <int NSLOT>
 __device__ __forceinline__ void append_rays(const bool (&has)[NSLOT], const float4 (&o)[NSLOT], const float4 (&d)[NSLOT],
                                             const float4 (&p)[NSLOT], RayQueue out, uint32_t* out_count) {
@@ -898,9 +921,7 @@ __device__ __forceinline__ void append_rays(const bool (&has)[NSLOT], const floa
         offs[s] = total + __popcll(m & lt);
         total += __popcll(m);
     }
-    uint32_t base = 0;
-    if (lane_id == 0 && total) base = atomicAdd(out_count, total);
-    base = __shfl(base, 0);
+    const uint32_t base = block_reserve(total, out_count);
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
         if (has[s]) {
@@ -925,6 +946,7 @@ __device__ __forceinline__ void add_radiance(FrameDev fb, uint32_t pid, f3 c) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                                FrameDev fb) {
+    stage_srgb_lut(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 ro = rays.o[i], rd = rays.d[i];
@@ -935,14 +957,12 @@ __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQ
         c = sample_environment(sc, ld3(rd));
     } else {
         const uint32_t object = h1 & 0x3fffffffu;
-        const DevMesh mesh = sc.meshes[sc.objects[object].mesh_index];
-        const uint32_t* ix = sc.indices + mesh.first_index + __float_as_uint(h0.w);
-        const float4 c1 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[0]) * 3 + 2];
-        const float4 c2 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[1]) * 3 + 2];
-        const float4 c3 = sc.vertices[static_cast<size_t>(mesh.first_vertex + ix[2]) * 3 + 2];
+        const DevObject* obj = sc.objects + object;
+        const float4* rec = sc.corners + static_cast<size_t>(obj->tri_base + __float_as_uint(h0.w) / 3u) * 9u;
+        const float4 c1 = rec[2], c2 = rec[5], c3 = rec[8];
         const float A = h0.y, B = h0.z, C = 1.0f - A - B;
         const float u = lin3(c1.z, c2.z, c3.z, A, B, C), v = lin3(c1.w, c2.w, c3.w, A, B, C);
-        const float4 a = sample_albedo(sc, sc.materials[mesh.material], u, v);
+        const float4 a = sample_albedo(sc, obj->mat, u, v);
         c = f3{a.x, a.y, a.z};
     }
     add_radiance(fb, __float_as_uint(ro.w), c);
@@ -972,7 +992,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
         } else if (depth != 0) {
             ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             normals_to_world(sp);
-            const DevMaterial& mat = sc.materials[sp.material];
+            const DevMaterial& mat = sp.obj->mat;
             if ((h1 & 0x40000000u) && mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;
             tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
             const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
@@ -990,12 +1010,9 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
     }
     // every spawning lane emits ao_samples rays: wave-level reservation, sample-major order
     const unsigned long long mask = __ballot(spawn);
-    if (!mask) return;
     const uint32_t lane_id = threadIdx.x & 63u;
     const uint32_t n_spawn = __popcll(mask);
-    uint32_t base = 0;
-    if (lane_id == 0) base = atomicAdd(out_count, n_spawn * ao_samples);
-    base = __shfl(base, 0);
+    const uint32_t base = block_reserve(n_spawn * ao_samples, out_count);
     if (!spawn) return;
     const uint32_t rank = __popcll(mask & ((1ull << lane_id) - 1ull));
     const float inv = 1.0f / static_cast<float>(ao_samples);
@@ -1025,6 +1042,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 #endif
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
+    stage_srgb_lut(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
     float4 no[4], nd[4], np[4];
@@ -1049,7 +1067,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             sp.p.position = xform(sp.obj->model, sp.p.position, 1.0f);
             normals_to_world(sp);
-            const DevMaterial& mat = sc.materials[sp.material];
+            const DevMaterial& mat = sp.obj->mat;
             bool exiting = false;
             if (backface) {
                 if (mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;

@@ -127,7 +127,7 @@ struct ptgpu_ctx {
     bool scene_loaded = false, camera_set = false;
 
     // scene
-    DevBuf nodes, tris, instances, xforms, objects, meshes, vertices, indices, materials, images, texels, env, lut;
+    DevBuf nodes, tris, instances, xforms, objects, corners, texels, env, lut;
     ptd::SceneDev scene{};
     std::vector<ptgpu_bvh_info> bvh_info;
     std::vector<uint32_t> object_mesh;  // object -> mesh index (for hit dumps)
@@ -598,27 +598,71 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     std::memcpy(c->scene_max, table.scene_max, 12);
 
     // ---- shading data ----
+    // corners: every triangle's three vertices de-indexed, in mesh order (the hit record's triangle index / 3)
+    std::vector<uint64_t> mesh_tri_base(model->n_meshes);
+    uint64_t n_shade_tris = 0;
+    for (uint32_t i = 0; i < model->n_meshes; ++i) {
+        mesh_tri_base[i] = n_shade_tris;
+        n_shade_tris += model->meshes[i].n_indices / 3;
+    }
+    if (n_shade_tris >= (1ull << 32)) return c->fail(PTGPU_E_INVALID, "scene exceeds 2^32 triangles");
+    std::vector<ptgpu_vertex> corners(static_cast<size_t>(n_shade_tris) * 3);
+    for (uint32_t i = 0; i < model->n_meshes; ++i) {
+        const ptgpu_mesh& m = model->meshes[i];
+        ptgpu_vertex* dst = corners.data() + mesh_tri_base[i] * 3;
+        const uint32_t n_corner = m.n_indices - m.n_indices % 3;
+        for (uint32_t k = 0; k < n_corner; ++k) {
+            const uint32_t v = model->indices[m.first_index + k];
+            if (v >= m.n_vertices) return c->fail(PTGPU_E_INVALID, "mesh %u: index %u beyond its %u vertices", i, v, m.n_vertices);
+            dst[k] = model->vertices[m.first_vertex + v];
+        }
+    }
+    auto texture_of = [&](int32_t image, ptd::DevTexture& out) -> bool {
+        out = ptd::DevTexture{0, 0, 0u};
+        if (image < 0) return true;
+        if (static_cast<uint32_t>(image) >= model->n_images) return false;
+        const ptgpu_image& im = model->images[image];
+        if (im.width <= 0 || im.height <= 0 || im.texel_offset + static_cast<uint64_t>(im.width) * im.height > model->n_texels ||
+            im.texel_offset >= (1ull << 32))
+            return false;
+        out = ptd::DevTexture{im.width, im.height, static_cast<uint32_t>(im.texel_offset)};
+        return true;
+    };
     std::vector<ptd::DevObject> objects(model->n_objects);
     c->object_mesh.resize(model->n_objects);
     for (uint32_t i = 0; i < model->n_objects; ++i) {
         const ptgpu_object& o = model->objects[i];
+        ptd::DevObject& d = objects[i];
+        std::memset(&d, 0, sizeof(d));
         for (int col = 0; col < 4; ++col)
             for (int r = 0; r < 3; ++r) {
-                objects[i].model[col * 3 + r] = o.model_matrix[col * 4 + r];
-                objects[i].normal[col * 3 + r] = o.normal_matrix[col * 4 + r];
+                d.model[col * 3 + r] = o.model_matrix[col * 4 + r];
+                d.normal[col * 3 + r] = o.normal_matrix[col * 4 + r];
             }
-        objects[i].mesh_index = o.mesh_index;
+        d.tri_base = static_cast<uint32_t>(mesh_tri_base[o.mesh_index]);
         c->object_mesh[i] = o.mesh_index;
+        const ptgpu_material& m = model->materials[model->meshes[o.mesh_index].material_index];
+        ptd::DevMaterial& dm = d.mat;
+        std::memcpy(dm.base_color, m.base_color_factor, 16);
+        std::memcpy(dm.emissive, m.emissive_factor, 12);
+        dm.emissive_strength = m.emissive_strength;
+        std::memcpy(dm.attenuation, m.attenuation_factor, 12);
+        dm.metallic = m.metallic_factor;
+        dm.roughness = m.roughness_factor;
+        dm.ior = m.ior;
+        dm.f0 = m.dielectric_f0;
+        dm.transmission = m.transmission_factor;
+        dm.alpha_cutoff = m.alpha_cutoff;
+        dm.double_sided = m.double_sided != 0;
+        dm.has_volume = m.has_volume != 0;
+        dm.alpha_blending = m.alpha_blending != 0;
+        if (!texture_of(m.base_color_texture, dm.base_color_tex) || !texture_of(m.metallic_roughness_texture, dm.mr_tex) ||
+            !texture_of(m.normal_texture, dm.normal_tex) || !texture_of(m.transmission_texture, dm.transmission_tex) ||
+            !texture_of(m.emissive_texture, dm.emissive_tex))
+            return c->fail(PTGPU_E_INVALID, "object %u: its material names an image that does not exist or lies outside the texel array", i);
     }
-    std::vector<ptd::DevMesh> meshes(model->n_meshes);
-    for (uint32_t i = 0; i < model->n_meshes; ++i)
-        meshes[i] = {model->meshes[i].first_vertex, model->meshes[i].first_index, model->meshes[i].material_index,
-                     model->meshes[i].n_indices};
-    static_assert(sizeof(ptd::DevMaterial) == sizeof(ptgpu_material), "material layouts must match");
     static_assert(sizeof(ptgpu_vertex) == 48, "vertex is three float4");
-    std::vector<ptd::DevImage> images(model->n_images);
-    for (uint32_t i = 0; i < model->n_images; ++i)
-        images[i] = {model->images[i].width, model->images[i].height, static_cast<uint32_t>(model->images[i].texel_offset), 0u};
+    static_assert(sizeof(ptd::DevObject) == 256, "object record is 256 bytes");
     float lut[256];
     for (int i = 0; i < 256; ++i) lut[i] = srgb_to_linear_host(static_cast<float>(i) / 255.0f);
     const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // CPUTexture<hdr_pixel>::create_white_texture, cpu_framebuffer.cc:104
@@ -668,11 +712,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     if ((rc = upload(c, c->instances, table.instances.data(), table.instances.size()))) return rc;
     if ((rc = upload(c, c->xforms, table.xforms.data(), table.xforms.size()))) return rc;
     if ((rc = upload(c, c->objects, objects.data(), objects.size()))) return rc;
-    if ((rc = upload(c, c->meshes, meshes.data(), meshes.size()))) return rc;
-    if ((rc = upload(c, c->vertices, model->vertices, static_cast<size_t>(model->n_vertices)))) return rc;
-    if ((rc = upload(c, c->indices, model->indices, static_cast<size_t>(model->n_indices)))) return rc;
-    if ((rc = upload(c, c->materials, model->materials, model->n_materials))) return rc;
-    if ((rc = upload(c, c->images, images.data(), images.size()))) return rc;
+    if ((rc = upload(c, c->corners, corners.data(), corners.size()))) return rc;
     if ((rc = upload(c, c->texels, reinterpret_cast<const uint32_t*>(model->texels), static_cast<size_t>(model->n_texels)))) return rc;
     if ((rc = upload(c, c->env, env_px, static_cast<size_t>(env_w) * env_h * 4))) return rc;
     if ((rc = upload(c, c->lut, lut, 256))) return rc;
@@ -683,11 +723,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.instances = c->instances.as<ptd::DevInstance>();
     sc.xforms = c->xforms.as<ptd::DevXform>();
     sc.objects = c->objects.as<ptd::DevObject>();
-    sc.meshes = c->meshes.as<ptd::DevMesh>();
-    sc.vertices = c->vertices.as<float4>();
-    sc.indices = c->indices.as<uint32_t>();
-    sc.materials = c->materials.as<ptd::DevMaterial>();
-    sc.images = c->images.as<ptd::DevImage>();
+    sc.corners = c->corners.as<float4>();
     sc.texels = c->texels.as<uint32_t>();
     sc.env = c->env.as<float4>();
     sc.srgb_lut = c->lut.as<float>();
