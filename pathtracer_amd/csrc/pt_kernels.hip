@@ -318,19 +318,15 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 //                    ray, ended by a PT_NO_NODE slot.
 //   traverse_kernel  persistent: every lane is a small state machine and a wavefront keeps pulling rays from
 //                    a global cursor:
-//                        IDLE   no ray                      -> refill: claim the next ray
-//                        NEXT   ray needs its next instance -> accept the hit of the finished one, read the
-//                                                              next candidate, enter it or write the result
+//                        IDLE   no ray                      \  service: accept the hit of the finished instance,
+//                        NEXT   ray needs its next instance /  retire or claim a ray, enter the next candidate
 //                        INNER  current reference is a node -> one node step
 //                        LEAF   current reference is a leaf -> one triangle test
 //                    Per iteration the wavefront runs the phase that most lanes wait for, so its instructions
 //                    are shared.  A lane's own sequence of instance visits, node visits and triangle tests is
 //                    exactly that of the simple kernel above; only the interleaving across lanes changes.
-#ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 8
-#endif
-#ifndef PT_NEXT_MIN
-#define PT_NEXT_MIN 16
+#ifndef PT_SERVICE_MIN
+#define PT_SERVICE_MIN 24
 #endif
 #ifndef PT_BURST
 #define PT_BURST 8
@@ -476,38 +472,22 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                 cnt.census[phase][5] += n_leaf * steps;
             }
         };
-        if (!exhausted && n_idle >= PT_REFILL_MIN) {
-            // ================= refill: hand rays to the idle lanes =================
-            // The wavefront owns a block of PT_RAY_BLOCK consecutive rays claimed with ONE atomic on the global
-            // cursor (a single word sustains well under 100 M atomics/s, far less than the ray rate).
+        const uint32_t n_wait = n_next + (exhausted ? 0u : n_idle);  // lanes that a service pass can move on
+        if (n_wait && (n_wait >= PT_SERVICE_MIN || (n_inner + n_leaf) == 0u)) {
+            // ================= service: finish instances, hand out rays, enter instances =================
+            // One pass serves every lane that is not traversing, so a lane waits once between two instances
+            // instead of once per kind of service:
+            //   (1) lanes whose instance is finished accept its hit and pick their next candidate, or retire;
+            //   (2) idle lanes, the just retired ones included, claim new rays and pick their first candidate;
+            //   (3) all lanes that picked a candidate transform their ray into its object space together.
             if (COUNT) tally(0, 1);
-            if (local_next >= local_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(next_ray, static_cast<uint32_t>(PT_RAY_BLOCK));
-                base = __builtin_amdgcn_readfirstlane(base);
-                local_next = base;
-                local_end = (base < n) ? ((n - base < PT_RAY_BLOCK) ? n : base + PT_RAY_BLOCK) : base;
-                if (base >= n) exhausted = true;
-            }
-            const uint32_t avail = local_end - local_next;
-            const uint32_t rank = __popcll(m_idle & lt_mask);
-            if (cur == PT_IDLE && rank < avail) {
-                rid = local_next + rank;
-                cursor = 0;
-                flags = 0;
-                b_t = kInfF;
-                slot = PT_NO_NODE;
-                cur = PT_NO_NODE;
-                h_hit = false;
-            }
-            local_next += (n_idle < avail) ? n_idle : avail;
-        } else if (n_next && (n_next >= PT_NEXT_MIN || (n_inner + n_leaf) == 0u)) {
-            // ================= next instance: accept the finished one's hit, enter the next candidate =================
-            if (COUNT) tally(1, 1);
-            if (cur == PT_NO_NODE) {
+            uint32_t enter_slot = PT_NO_NODE;
+            f3 ow = mk3(0.0f), dw = mk3(0.0f);
+            auto pick = [&](bool fresh) {
                 const float4 ro = ray_o[rid], rd = ray_d[rid];
-                const f3 ow = ld3(ro), dw = ld3(rd);
-                if (slot == PT_NO_NODE) {
+                ow = ld3(ro);
+                dw = ld3(rd);
+                if (fresh) {
                     if ((__float_as_uint(rd.w) >> 8) & 1u) flags |= F_ANY;
                 } else if (h_hit) {
                     // back to a world-space distance and acceptance (acceleration_structure.cc:704-706, 616-623)
@@ -523,7 +503,6 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     }
                 }
                 const bool any_hit = (flags & F_ANY) != 0;
-                uint32_t next_slot = PT_NO_NODE;
                 if (!(any_hit && (flags & F_BHIT))) {
                     uint2 e;
                     if (cursor < kCandMax) {
@@ -534,30 +513,58 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                         if (e.y != PT_NO_NODE) cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid] = e;
                     }
                     ++cursor;
-                    if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) next_slot = e.y;
+                    if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) enter_slot = e.y;
                 }
-                if (next_slot == PT_NO_NODE) {
+                if (enter_slot == PT_NO_NODE) {  // the ray is done
                     if (!(flags & F_BHIT)) {
                         hit0[rid] = make_float4(kInfF, 0.0f, 0.0f, 0.0f);
                         hit1[rid] = 0u;
                     }
                     cur = PT_IDLE;
-                    slot = PT_NO_NODE;
-                } else {
-                    if (COUNT) ++cnt.inst_entered;
-                    slot = next_slot;
-                    const DevXform& xf = sc.xforms[slot];
-                    o = xform(xf.inv, ow, 1.0f);
-                    d = normalize3(xform(xf.inv, dw, 0.0f));
-                    inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
-                    flags &= ~(F_CULL | F_SLOW);
-                    if (xf.cull) flags |= F_CULL;
-                    const bool finite = (fabsf(inv.x) < kInfF) && (fabsf(inv.y) < kInfF) && (fabsf(inv.z) < kInfF);
-                    if (!finite) flags |= F_SLOW;
-                    h_t = kInfF; h_A = 0.0f; h_B = 0.0f; h_tri = 0; h_hit = false; h_back = false;
-                    sp = 0;
-                    cur = xf.root;
                 }
+            };
+            if (cur == PT_NO_NODE) pick(false);
+            bool fresh = false;
+            if (!exhausted) {
+                // The wavefront owns a block of PT_RAY_BLOCK consecutive rays claimed with ONE atomic on the global
+                // cursor (a single word sustains well under 100 M atomics/s, far less than the ray rate).
+                const unsigned long long m_free = __ballot(cur == PT_IDLE);
+                const uint32_t n_free = __popcll(m_free);
+                if (n_free && local_next >= local_end) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(next_ray, static_cast<uint32_t>(PT_RAY_BLOCK));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    local_next = base;
+                    local_end = (base < n) ? ((n - base < PT_RAY_BLOCK) ? n : base + PT_RAY_BLOCK) : base;
+                    if (base >= n) exhausted = true;
+                }
+                const uint32_t avail = local_end - local_next;
+                const uint32_t rank = __popcll(m_free & lt_mask);
+                if (cur == PT_IDLE && rank < avail) {
+                    rid = local_next + rank;
+                    cursor = 0;
+                    flags = 0;
+                    b_t = kInfF;
+                    h_hit = false;
+                    fresh = true;
+                }
+                local_next += (n_free < avail) ? n_free : avail;
+            }
+            if (fresh) pick(true);
+            if (enter_slot != PT_NO_NODE) {
+                if (COUNT) ++cnt.inst_entered;
+                slot = enter_slot;
+                const DevXform& xf = sc.xforms[slot];
+                o = xform(xf.inv, ow, 1.0f);
+                d = normalize3(xform(xf.inv, dw, 0.0f));
+                inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
+                flags &= ~(F_CULL | F_SLOW);
+                if (xf.cull) flags |= F_CULL;
+                const bool finite = (fabsf(inv.x) < kInfF) && (fabsf(inv.y) < kInfF) && (fabsf(inv.z) < kInfF);
+                if (!finite) flags |= F_SLOW;
+                h_t = kInfF; h_A = 0.0f; h_B = 0.0f; h_tri = 0; h_hit = false; h_back = false;
+                sp = 0;
+                cur = xf.root;
             }
         } else if (n_inner && n_inner >= n_leaf) {
             // ================= inner-node steps for the lanes that hold a node =================

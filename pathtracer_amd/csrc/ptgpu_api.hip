@@ -139,7 +139,11 @@ struct ptgpu_ctx {
     float origin[3];
 
     // work memory
-    uint32_t chunk = 1u << 22;     // rays per launch and camera samples per batch (PTGPU_CHUNK)
+    // Upper bound of rays per launch and of camera samples per batch (PTGPU_CHUNK).  Large on purpose: every launch
+    // of the persistent extend kernel ends with a tail in which a few long rays keep nearly empty wavefronts
+    // alive, so throughput grows with the launch size (about +18 % from 8 Mi to 64 Mi rays), and the memory is there.
+    uint32_t chunk = 1u << 26;
+    uint32_t launch_cap = 0;       // rays per launch the work buffers are sized for (also the candidate list stride)
     Pool pools[2];
     DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand;
     bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
@@ -223,8 +227,8 @@ uint32_t fanout_of(const ptgpu_settings& s) {
     return 0;
 }
 
-int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces) {
-    const uint64_t K = c->chunk;
+int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t K) {
+    K = std::max<uint64_t>(K, c->launch_cap);
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
@@ -252,6 +256,7 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces) {
     if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * K * sizeof(uint2)));
     PT_HIP(c, c->counter.ensure(16));
     PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
+    c->launch_cap = static_cast<uint32_t>(K);
     return PTGPU_OK;
 }
 
@@ -259,11 +264,11 @@ void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t 
                 ptd::TraceCounters* tc, hipEvent_t between = nullptr) {
     const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     if (c->persistent)
-        ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->chunk},
+        ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->launch_cap},
                                       c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(), tc,
                                       between);
     else
-        ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->chunk, tc);
+        ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->launch_cap, tc);
 }
 
 struct RenderOut {
@@ -291,9 +296,13 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     const uint32_t ao_samples = c->scene_settings.max_new_rays_per_bounce;
     const uint32_t bounces = s.max_ray_bounces & 0xffu;  // static_cast<uint8_t>, renderer.cc:73
 
-    int rc = ensure_work_memory(c, fanout, bounces);
-    if (rc) return rc;
     const FrameGeometry g = frame_geometry(c, width, height);
+    // camera samples are generated in equal batches of at most `chunk`; a batch is also the largest launch
+    const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
+    const uint64_t n_batches = std::max<uint64_t>((total + c->chunk - 1) / c->chunk, 1);
+    const uint64_t K = std::max<uint64_t>((((total + n_batches - 1) / n_batches) + 63ull) & ~63ull, 64);
+    int rc = ensure_work_memory(c, fanout, bounces, K);
+    if (rc) return rc;
     PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
     ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride};
     ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3);  // framebuffer.clear, renderer.cc:85
@@ -308,8 +317,6 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     uint32_t* d_count = c->counter.as<uint32_t>();
 
     ptgpu_stats out{};
-    const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
-    const uint64_t K = c->chunk;
     PT_HIP(c, hipEventRecord(c->ev[4], st));
     // Generation-ordered schedule.  A frame says "drain pool `pool` down to floor_in, spawned rays go on top of
     // the other pool (which holds older rays up to floor_out)".  A generation is consumed from the top of its pool
@@ -830,16 +837,16 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     const uint32_t spp = c->settings.samples_per_pixel ? c->settings.samples_per_pixel : 1;
     if (sample >= spp) return c->fail(PTGPU_E_INVALID, "render_hits: sample %u >= samples per pixel %u", sample, spp);
     PT_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_work_memory(c, 0, 0);
+    const FrameGeometry g = frame_geometry(c, width, height);
+    const uint64_t total = static_cast<uint64_t>(g.n_tiles) * 64ull;
+    const uint64_t K = std::min<uint64_t>(std::min<uint64_t>(c->chunk, 1u << 22), total);
+    int rc = ensure_work_memory(c, 0, 0, K);
     if (rc) return rc;
     hipStream_t st = c->stream;
-    const FrameGeometry g = frame_geometry(c, width, height);
     const std::vector<float> sub = subsample_table(spp);
     PT_HIP(c, c->subs.ensure(sub.size() * 4));
     PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
-    const uint64_t total = static_cast<uint64_t>(g.n_tiles) * 64ull;
-    const uint64_t K = c->chunk;
     std::vector<float4> h0, ro;
     std::vector<uint32_t> h1;
     for (uint64_t first = 0; first < total; first += K) {
@@ -877,10 +884,10 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
     if (!c || (n && (!origins || !directions || !out))) return PTGPU_E_INVALID;
     if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays: no scene loaded");
     PT_HIP(c, hipSetDevice(c->device));
-    int rc = ensure_work_memory(c, 0, 0);
+    const uint64_t K = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(c->chunk, 1u << 22), n), 64);
+    int rc = ensure_work_memory(c, 0, 0, K);
     if (rc) return rc;
     hipStream_t st = c->stream;
-    const uint64_t K = c->chunk;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     DevBuf d_o, d_d, d_a;
     PT_HIP(c, d_o.ensure(K * 12));
