@@ -234,6 +234,15 @@ def main() -> None:
             tlas_bytes_per_ray = I * 64 + 32 + (E + 1) * 8
             traverse_s = traverse_ms / 1e3
             achieved = (rays * bytes_per_ray) / traverse_s / 1e9
+            # HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
+            # this same command, tools/profile_bench.sh): bytes per ray of that run x the rays of one launch here
+            traffic = None
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                k = tj.get("kernels", {}).get("traverse_kernel<false>")
+                if k and tj.get("workload") == line["config"]["workload"]:
+                    traffic = round((k["fetch_bytes_per_ray"] + k["write_bytes_per_ray"]) * rays / max(extend_launches, 1))
             line["roofline"] = {
                 "kernel": "traverse_kernel<false>",
                 "bound": "hbm",
@@ -241,7 +250,8 @@ def main() -> None:
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(bytes_per_ray * rays / max(extend_launches, 1)),
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "per_ray": {"nodes_64B": round(V, 3), "triangles_48B": round(T, 3),
                             "instances_entered_128B_plus_8B": round(E, 3), "ray_read_B": 32, "hit_write_B": 20},

@@ -656,6 +656,29 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
 // ---------------------------------------------------------------------------------------------
 // generate
 // ---------------------------------------------------------------------------------------------
+// Reserves `wave_total` consecutive queue slots for the calling wavefront with ONE atomic per workgroup: a single
+// counter word sustains well under 100 M atomics/s, which one atomic per wavefront would exceed at the
+// kernel's ray rate.  Every thread of the workgroup must call it.
+__device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t* out_count) {
+    __shared__ uint32_t s_tot[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) s_tot[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) t += s_tot[w];
+        s_base = t ? atomicAdd(out_count, t) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = s_base;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w)
+        if (static_cast<uint32_t>(w) < wave) base += s_tot[w];
+    return base;
+}
+
 __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const float2* __restrict__ sub,
                                                           uint32_t sample_begin, uint32_t sample_step,
                                                           uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
@@ -693,12 +716,10 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
             p4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_camera_key(seed, pixel, sample)));
         }
     }
-    // wavefront compaction: one atomic per wave, rays of a wave stay contiguous and ordered
+    // compaction: rays of a wave stay contiguous and ordered
     const unsigned long long mask = __ballot(valid);
     const uint32_t lane_id = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane_id == 0 && mask) base = atomicAdd(out_count, static_cast<uint32_t>(__popcll(mask)));
-    base = __shfl(base, 0);
+    const uint32_t base = block_reserve(static_cast<uint32_t>(__popcll(mask)), out_count);
     if (valid) {
         const uint32_t dst = base + __popcll(mask & ((1ull << lane_id) - 1ull));
         out.o[dst] = o4;
@@ -889,29 +910,6 @@ __device__ __forceinline__ void normals_to_world(ShadePoint& sp) {
     sp.p.tangent = make_float4(t.x, t.y, t.z, 0.0f);
     sp.p.normal = xform(sp.obj->normal, sp.p.normal, 0.0f);
     sp.bitangent = cross3(sp.p.normal, t) * sign;
-}
-
-// Reserves `wave_total` consecutive queue slots for the calling wavefront with ONE atomic per workgroup: a single
-// counter word sustains well under 100 M atomics/s, which one atomic per wavefront would exceed at the
-// kernel's ray rate.  Every thread of the workgroup must call it.
-__device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t* out_count) {
-    __shared__ uint32_t s_tot[kBlock / 64];
-    __shared__ uint32_t s_base;
-    const uint32_t wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63u) == 0) s_tot[wave] = wave_total;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) t += s_tot[w];
-        s_base = t ? atomicAdd(out_count, t) : 0u;
-    }
-    __syncthreads();
-    uint32_t base = s_base;
-#pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
-        if (static_cast<uint32_t>(w) < wave) base += s_tot[w];
-    return base;
 }
 
 // append of up to NSLOT rays per lane: slot-major order inside a wave keeps rays of one lobe contiguous

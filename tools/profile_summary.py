@@ -7,7 +7,11 @@ import glob
 import re
 import sys
 
+import json
 root = sys.argv[1]
+bench = json.loads(open(root + "/bench.json").read().strip().splitlines()[-1])
+rays_per_step = bench["value"] * 1e6 * bench["ms_per_step"] / 1e3
+traffic = {"workload": bench["config"]["workload"], "rays_per_step": rays_per_step, "kernels": {}}
 
 
 def short(name):
@@ -33,3 +37,7 @@ for tag, scale in (("fetch", 2.0), ("write", 1.0)):
     for (k, c), v in sorted(acc.items()):
         print(f"{k:32s} {c:12s} dispatches {cnt[(k, c)]:7d} total_GB {v*1024*scale/1e9:10.3f} "
               f"per_launch_MB {v*1024*scale/cnt[(k, c)]/1e6:10.3f}")
+        if k.endswith("_kernel<false>") or k in ("shade_pbr_kernel", "generate_kernel"):
+            # the counter passes render ONE step, so bytes / rays_per_step is the HBM-side traffic per ray
+            traffic["kernels"].setdefault(k, {})[tag + "_bytes_per_ray"] = v * 1024 * scale / rays_per_step
+open(root + "/hbm_traffic.json", "w").write(json.dumps(traffic, indent=1) + "\n")
