@@ -1,0 +1,165 @@
+// app_model.h — the data contract of the reference's host side, as the C++ caller sees it.
+//
+// Same type and member names as the reference (src/model_loader.h:14-65, src/render_settings.h:7-21,
+// src/arguments.h:10-25, src/cpu_framebuffer.h:29-157) so that code written against the reference's
+// Renderer compiles against this one.  glm and fastgltf are not available here; the few vector types the
+// interface needs are small PODs with the same element order (column-major matrices, xyzw vectors).
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <filesystem>
+#include <optional>
+#include <string>
+#include <vector>
+
+namespace app {
+
+struct fvec2 {
+    float x = 0, y = 0;
+};
+struct fvec3 {
+    float x = 0, y = 0, z = 0;
+    float& operator[](int i) { return (&x)[i]; }
+    const float& operator[](int i) const { return (&x)[i]; }
+};
+struct fvec4 {
+    float x = 0, y = 0, z = 0, w = 0;
+    float& operator[](int i) { return (&x)[i]; }
+    const float& operator[](int i) const { return (&x)[i]; }
+};
+struct ivec2 {
+    int x = 0, y = 0;
+};
+struct fmat4x4 {  // column-major, m[c] is column c (glm layout)
+    fvec4 m[4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    fvec4& operator[](int c) { return m[c]; }
+    const fvec4& operator[](int c) const { return m[c]; }
+};
+inline fvec3 xyz(const fvec4& v) { return fvec3{v.x, v.y, v.z}; }
+
+enum class RayProgramMode { RayCaster, AmbientOcclusion, PBR, kNum };   // src/arguments.h:10-16
+enum class AccelerationStructureType { Naive, BVH, kNum };              // src/arguments.h:18-23
+enum class DefaultEnvironment { Black, White };
+
+struct RenderSettings {  // src/render_settings.h:7-21
+    unsigned int samplesPerPixel = 1;
+    unsigned int maxRayBounces = 0;
+    unsigned int maxNewRaysPerBounce = 0;
+    unsigned int maxTrianglesPerBVHLeaf = 8;
+    float envmapRotation = 0;  // in radians
+    RayProgramMode programMode = RayProgramMode::RayCaster;
+    AccelerationStructureType accelStructType = AccelerationStructureType::Naive;
+    bool operator==(const RenderSettings& other) const = default;
+};
+
+// stands in for fastgltf::Camera::Perspective (same members)
+struct Perspective {
+    std::optional<float> aspectRatio;
+    float yfov = 1.0471975512f;
+    std::optional<float> zfar;
+    float znear = 0.1f;
+};
+
+using sdr_pixel = std::array<std::uint8_t, 4>;
+using hdr_pixel = fvec4;
+
+template <typename pixel>
+class CPUTexture {  // src/cpu_framebuffer.h:64-131 (storage and construction; sampling runs on the device)
+  public:
+    CPUTexture() = default;
+    explicit CPUTexture(const std::filesystem::path& path);  // Radiance .hdr (hdr_pixel only)
+    CPUTexture(pixel initial_col) : data_(1, initial_col), width_(1), height_(1) {}
+    CPUTexture(int width, int height, std::vector<pixel> data) : data_(std::move(data)), width_(width), height_(height) {}
+
+    int width() const { return width_; }
+    int height() const { return height_; }
+    const pixel* data() const { return data_.data(); }
+
+    static CPUTexture create_white_texture();
+    static CPUTexture create_black_texture();
+
+  protected:
+    std::vector<pixel> data_;
+    int width_ = 1;
+    int height_ = 1;
+};
+
+class CPUFrameBuffer : private CPUTexture<hdr_pixel> {  // src/cpu_framebuffer.h:133-155
+  public:
+    CPUFrameBuffer();
+    CPUFrameBuffer(int width, int height);
+    void clear(const hdr_pixel clearColor = hdr_pixel{0.0f, 0.0f, 0.0f, 1.0f});
+    hdr_pixel& at(int x, int y);
+    const hdr_pixel& at(int x, int y) const;
+    using CPUTexture::height;
+    using CPUTexture::width;
+    float* raw() { return &data_[0].x; }
+    // ".png": clamp, sRGB-encode all four channels, 8 bit; anything else: Radiance RGBE (src/cpu_framebuffer.cc:125-148)
+    void save_to_file(const std::filesystem::path& filePath) const;
+};
+
+struct vertex {  // src/model_loader.h:14-19
+    fvec3 position;
+    fvec3 normal;
+    fvec4 tangent;
+    fvec2 uv;
+};
+struct Mesh {  // a glTF primitive
+    std::vector<std::uint32_t> indices;
+    std::vector<vertex> vertices;
+    uint32_t materialIndex = 0;
+};
+struct Object {
+    fmat4x4 ModelMatrix;
+    fmat4x4 NormalMatrix;
+    uint32_t meshIndex = 0;
+};
+struct Material {  // src/model_loader.h:33-52
+    fvec4 baseColorFactor{1.0f, 1.0f, 1.0f, 1.0f};
+    fvec3 emissiveFactor{0.0f, 0.0f, 0.0f};
+    fvec3 attenuationFactor{0.0f, 0.0f, 0.0f};
+    float metallicFactor = 1.0f;
+    float roughnessFactor = 1.0f;
+    int baseColorTextureIndex = -1;
+    int metallicRoughnessTextureIndex = -1;
+    int normalTextureIndex = -1;
+    float ior = 1.5f;
+    float dielectric_f0 = 0.04f;
+    float transmisionFactor = 0.0f;
+    int transmissionTextureIndex = -1;
+    int emissiveTextureIndex = -1;
+    float emissiveStrength = 1.0f;
+    bool doubleSided = false;
+    bool hasVolume = false;
+    bool alphaBlending = false;
+    float alpha_cutoff = -1.0f;
+};
+struct Camera {
+    fmat4x4 ModelMatrix;
+    Perspective camera_params;  // orthographic cameras are not snapped to in the reference either (src/viewer.cc:69-71)
+};
+struct Model {  // src/model_loader.h:59-65
+    std::vector<Camera> cameras_;
+    std::vector<Material> materials_;
+    std::vector<Mesh> meshes_;
+    std::vector<Object> objects_;
+    std::vector<CPUTexture<sdr_pixel>> images_;
+};
+
+struct BBox {  // src/acceleration_structure.h (min/max corners)
+    fvec3 min, max;
+};
+
+// Reads the flat scene container written by pathtracer_amd.model.SceneModel.save (magic "PTSC0001"):
+// the stand-in for ModelLoader::loadFromFile + constructModel while no glTF reader exists.
+class ModelLoader {
+  public:
+    bool loadFromFile(std::filesystem::path path);
+    Model constructModel() const { return model_; }
+
+  private:
+    Model model_;
+};
+
+}  // namespace app

@@ -1,0 +1,134 @@
+// PathTracer — command line of the reference (src/main.cc:12-62, src/arguments.cc:28-147) above the GPU renderer.
+// Same flags, defaults, stdout lines and exit codes; -f takes the flat scene container ("PTSC0001") until a glTF
+// reader exists.  Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw
+// ptgpu_hit records, row-major) and --stats.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+
+#include "app_renderer.h"
+
+namespace {
+
+struct Args {
+    std::string model, env = "white", output = "snapshot.hdr", dump_hits;
+    int program = 3, as = 2, samples = 1, bounces = 4, newrays = 0, env_rot = 0, max_leaf = 8, width = 800, height = 600;
+    unsigned seed = 0;
+    int device = 0;
+    bool stats = false;
+};
+
+const char* kUsage =
+    "Usage: PathTracer -f <scene.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2]\n"
+    "                  [-s samples] [-b bounces] [-r newrays] [--env_rot degrees] [-m max_leaf_triangles]\n"
+    "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats]\n"
+    "Use -h or --help for usage info.\n";
+
+bool parse(int argc, char** argv, Args& a) {
+    auto need = [&](int& i) -> const char* {
+        if (i + 1 >= argc) {
+            std::cerr << "missing value after " << argv[i] << "\n" << kUsage;
+            return nullptr;
+        }
+        return argv[++i];
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string k = argv[i];
+        const char* v = nullptr;
+        auto num = [&](int& dst) { if (!(v = need(i))) return false; dst = std::atoi(v); return true; };
+        if (k == "-h" || k == "--help") { std::cout << kUsage; return false; }
+        else if (k == "-f" || k == "--file") { if (!(v = need(i))) return false; a.model = v; }
+        else if (k == "-e" || k == "--env") { if (!(v = need(i))) return false; a.env = v; }
+        else if (k == "-o" || k == "--output") { if (!(v = need(i))) return false; a.output = v; }
+        else if (k == "--dump-hits") { if (!(v = need(i))) return false; a.dump_hits = v; }
+        else if (k == "-p" || k == "--program") { if (!num(a.program)) return false; }
+        else if (k == "-a" || k == "--as") { if (!num(a.as)) return false; }
+        else if (k == "-s" || k == "--samples") { if (!num(a.samples)) return false; }
+        else if (k == "-b" || k == "--bounces") { if (!num(a.bounces)) return false; }
+        else if (k == "-r" || k == "--newrays") { if (!num(a.newrays)) return false; }
+        else if (k == "--env_rot") { if (!num(a.env_rot)) return false; }
+        else if (k == "-m") { if (!num(a.max_leaf)) return false; }
+        else if (k == "--width") { if (!num(a.width)) return false; }
+        else if (k == "--height") { if (!num(a.height)) return false; }
+        else if (k == "--device") { if (!num(a.device)) return false; }
+        else if (k == "--seed") { if (!(v = need(i))) return false; a.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10)); }
+        else if (k == "--stats") { a.stats = true; }
+        else { std::cerr << "unknown argument " << k << "\n" << kUsage; return false; }
+    }
+    if (a.model.empty()) { std::cerr << "-f is required\n" << kUsage; return false; }
+    if (a.program < 1 || a.program > 3 || a.as < 1 || a.as > 2 || a.samples < 1 || a.bounces < 0 || a.newrays < 0 || a.max_leaf < 1 ||
+        a.width < 1 || a.height < 1) {
+        std::cerr << "argument out of range\n" << kUsage;
+        return false;
+    }
+    return true;
+}
+
+long ms_since(std::chrono::high_resolution_clock::time_point t0) {
+    return static_cast<long>(std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::high_resolution_clock::now() - t0).count());
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    using namespace app;
+    Args args;
+    if (!parse(argc, argv, args)) return 1;
+    try {
+        auto start = std::chrono::high_resolution_clock::now();
+        Model model;
+        {
+            ModelLoader loader{};
+            if (!loader.loadFromFile(args.model)) {
+                std::cerr << "Failed to load model from " << args.model << '\n';
+                return 1;
+            }
+            model = loader.constructModel();
+        }
+        CPUTexture<hdr_pixel> environment_texture;
+        if (args.env == "white") environment_texture = CPUTexture<hdr_pixel>::create_white_texture();
+        else if (args.env == "black") environment_texture = CPUTexture<hdr_pixel>::create_black_texture();
+        else environment_texture = CPUTexture<hdr_pixel>(std::filesystem::path(args.env));
+        std::cout << "loaded in " << ms_since(start) << " ms." << '\n';
+
+        RenderSettings settings;  // RenderSettings(const ConsoleArgs&), src/render_settings.cc:5-14
+        settings.samplesPerPixel = static_cast<unsigned>(args.samples);
+        settings.maxRayBounces = static_cast<unsigned>(args.bounces);
+        settings.maxNewRaysPerBounce = static_cast<unsigned>(args.newrays);
+        settings.maxTrianglesPerBVHLeaf = static_cast<unsigned>(args.max_leaf);
+        settings.envmapRotation = static_cast<float>(args.env_rot) * 0.01745329251994329576923690768489f;
+        settings.programMode = static_cast<RayProgramMode>(args.program - 1);
+        settings.accelStructType = static_cast<AccelerationStructureType>(args.as - 1);
+
+        Viewer viewer(std::move(model), std::move(environment_texture), settings, args.device);
+        viewer.renderer().set_seed(args.seed);
+        viewer.resize_window(ivec2{args.width, args.height});
+        viewer.snap_to_camera();
+
+        start = std::chrono::high_resolution_clock::now();
+        viewer.render();
+        std::cout << "rendered in " << ms_since(start) << " ms." << '\n';
+        if (args.stats) {
+            const ptgpu_stats& s = viewer.renderer().last_stats();
+            std::cout << "rays " << s.rays << " samples " << s.camera_samples << " gpu_ms " << s.total_ms << " extend_ms " << s.extend_ms
+                      << " shade_ms " << s.shade_ms << " Mrays/s " << (s.total_ms > 0 ? s.rays / s.total_ms / 1e3 : 0.0) << '\n';
+        }
+
+        start = std::chrono::high_resolution_clock::now();
+        viewer.take_snapshot(args.output);
+        if (!args.dump_hits.empty()) {
+            const std::vector<ptgpu_hit> hits = viewer.renderer().render_hits(args.width, args.height, 0);
+            std::ofstream f(args.dump_hits, std::ios::binary);
+            f.write(reinterpret_cast<const char*>(hits.data()), static_cast<std::streamsize>(hits.size() * sizeof(ptgpu_hit)));
+        }
+        std::cout << "output saved in " << ms_since(start) << " ms." << '\n';
+    } catch (const std::exception& e) {
+        std::cerr << "error: " << e.what() << '\n';
+        return 1;
+    }
+    return 0;
+}

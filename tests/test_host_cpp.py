@@ -1,0 +1,103 @@
+"""The C++ host (Renderer / Viewer / PathTracer command line) above the C ABI.
+
+CPU tests: the command line keeps the reference's contract for usage errors (src/main.cc:16-19, 27-30: exit
+code 1) and fails loudly, not silently, when no GPU is there.  GPU tests: the command line renders the same
+pixels and hit records as the Python mirror of the same interface, and its PNG / Radiance writers produce what
+the Python writers produce.
+"""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import helpers as H
+from pathtracer_amd import abi, image_io, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "pathtracer_amd", "bin", "PathTracer")
+
+needs_cli = pytest.mark.skipif(not os.path.exists(CLI), reason="C++ host not built (run __graft_entry__.build())")
+
+
+def run(*args):
+    return subprocess.run([CLI, *map(str, args)], capture_output=True, text=True, timeout=300)
+
+
+def read_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(tag + body) & 0xffffffff)
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert (depth, ctype) == (8, 6)
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 4)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+@needs_cli
+def test_cli_usage_errors():
+    r = run("-h")
+    assert r.returncode == 1 and "Usage: PathTracer" in r.stdout
+    r = run()
+    assert r.returncode == 1 and "-f is required" in r.stderr
+    r = run("-f", "/nonexistent/scene.ptsc")
+    assert r.returncode == 1 and "Failed to load model from" in r.stderr
+    r = run("-f", "x", "-p", "7")
+    assert r.returncode == 1 and "out of range" in r.stderr
+
+
+@needs_cli
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    scene = tmp_path / "tiny.ptsc"
+    scenes.tiny_scene().save(str(scene))
+    r = run("-f", scene, "-o", tmp_path / "o.hdr", "--width", 16, "--height", 8)
+    assert r.returncode == 1 and "ptgpu_create failed" in r.stderr
+    assert not (tmp_path / "o.hdr").exists()
+
+
+@needs_cli
+@pytest.mark.gpu
+def test_cli_matches_python_mirror(tmp_path):
+    model = scenes.tiny_scene()
+    scene = tmp_path / "tiny.ptsc"
+    model.save(str(scene))
+    w, h = 64, 40
+    hits_path, png, hdr = tmp_path / "hits.bin", tmp_path / "o.png", tmp_path / "o.hdr"
+    # config "plumbing": ray caster, BVH, 1 sample, white environment
+    r = run("-f", scene, "-p", 1, "-a", 2, "-s", 1, "--width", w, "--height", h, "--seed", 1234, "-o", png, "--dump-hits",
+            hits_path, "--stats")
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    assert "loaded in" in out and "rendered in" in out and "output saved in" in out
+    g = H.make_gpu(model, None, H.settings(program=0, spp=1, bounces=4), w, h)
+    img, _ = H.gpu_render(g, w, h)
+    assert np.array_equal(read_png(png), image_io.float_pixels_to_srgb8(img))
+    hits = np.fromfile(hits_path, dtype=abi.HIT_DTYPE).reshape(h, w)
+    ref = g.render_hits(w, h)
+    exact, _ = H.hits_equal(ref, hits)
+    assert exact.all()
+    # PBR with the HDR environment file, Radiance output
+    env_path = os.path.join(ROOT, "assets", "farmland_overcast_1k.hdr")
+    r = run("-f", scene, "-e", env_path, "-p", 3, "-a", 2, "-s", 4, "-b", 3, "--width", w, "--height", h, "--seed", 7, "-o", hdr)
+    assert r.returncode == 0, r.stderr
+    g = H.make_gpu(model, image_io.load_hdr(env_path), H.settings(program=2, spp=4, bounces=3, seed=7), w, h)
+    img, _ = H.gpu_render(g, w, h)
+    got = image_io.load_hdr(str(hdr))
+    # RGBE keeps 8 mantissa bits of the largest channel; float atomics make the two renders differ in the last bits
+    scale = np.maximum(img[..., :3].max(axis=-1, keepdims=True), 1e-6)
+    assert np.abs(got[..., :3] - img[..., :3]).max() <= (scale / 100.0).max()
+    assert (np.abs(got[..., :3] - img[..., :3]) <= scale / 100.0).all()
