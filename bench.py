@@ -235,7 +235,9 @@ def main() -> None:
             traverse_s = traverse_ms / 1e3
             achieved = (rays * bytes_per_ray) / traverse_s / 1e9
             # HBM-side bytes per launch from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over
-            # this same command, tools/profile_bench.sh): bytes per ray of that run x the rays of one launch here
+            # this same command, tools/profile_bench.sh): bytes per ray of that run x the rays of one launch here.
+            # FETCH_SIZE is taken as reported: the kernel reads random 64-byte sectors, for which the counter is exact
+            # (tools/micro/calibrate_fetch.sh); the doubling rule applies to streaming 128-byte requests only.
             traffic = None
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
             if os.path.exists(tpath):
@@ -251,6 +253,10 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5),
                 "traffic": traffic,
+                "traffic_GBps": (round(traffic / (traverse_ms / max(extend_launches, 1) * 1e-3) / 1e9, 1) if traffic else None),
+                "note": "algorithmic bytes count every node/triangle visit as a fetch; the scene is cache resident, so most "
+                        "are served by L1/L2 and frac can exceed 1 — traffic is what crosses the L2-fabric boundary "
+                        "(random 64-byte sector reads, measured ceiling 3.7 TB/s: tools/micro/gather_bench)",
                 "algorithmic_bytes_per_launch": round(bytes_per_ray * rays / max(extend_launches, 1)),
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "per_ray": {"nodes_64B": round(V, 3), "triangles_48B": round(T, 3),

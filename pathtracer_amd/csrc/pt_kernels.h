@@ -56,18 +56,21 @@ struct TraceCounters {   // filled by the counting variant of extend
     unsigned long long census[4][6];
 };
 
-// camera samples [first, first + n): index = (sample_slot * n_tiles + tile) * 64 + lane
+// slots_in_batch == 0: camera samples [first, first + n) of the linear index (sample_slot * n_tiles + tile) * 64 + lane.
+// slots_in_batch == S: sample slots [first, first + S) of every tile in tile-major order, n = S * n_tiles * 64.
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
-                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n, RayQueue out,
-                     uint32_t* out_count);
+                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
+                     uint32_t slots_in_batch, RayQueue out, uint32_t* out_count);
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters);
 // Workgroups that are resident at once for the persistent extend kernel (occupancy x compute units).
 uint32_t extend_persistent_grid(int device);
-// Persistent form: a fixed grid of n_blocks workgroups pulls rays from the cursor *next_ray (zeroed here).
+// Persistent form: a fixed grid of n_blocks workgroups pulls rays from 8 cursors, one per XCD segment of the queue,
+// 128 bytes apart at next_ray (1 KiB, zeroed here).
+// `overflow` (1 + n words) lists the rays handed to the continuation pass (more than kCandMax candidate instances).
 // `between`, when given, is recorded after the instance pass and before the traversal kernel.
 void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
-                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
+                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray, uint32_t* overflow,
                               TraceCounters* counters, hipEvent_t between = nullptr);
 // program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,

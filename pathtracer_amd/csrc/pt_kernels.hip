@@ -340,6 +340,41 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #define PT_RAY_BLOCK 128u
 #endif
 
+// Ray claiming of the persistent kernels.  The launch's rays are cut into 8 contiguous segments, one per XCD
+// (each XCD has its own L2, and neighbours in the queue are neighbours on the screen, so a segment's working set
+// is a part of the scene).  A wavefront claims blocks of PT_RAY_BLOCK rays from the segment of the XCD it runs
+// on with ONE atomic on that segment's cursor (a single word sustains well under 100 M atomics/s); when a
+// segment is used up it moves on to the next one, so every ray is claimed wherever the wavefronts were placed.
+struct RayClaim {
+    uint32_t seg, tried;         // current segment, segments found empty so far
+    uint32_t next, end;          // rays [next, end) are owned by this wavefront
+    bool exhausted;              // all 8 segments are used up (wave-uniform like the rest)
+};
+constexpr uint32_t kCursorStride = 32;  // cursors sit 128 bytes apart
+__device__ __forceinline__ RayClaim make_claim() {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return RayClaim{xcc & 7u, 0u, 0u, 0u, false};
+}
+__device__ __forceinline__ void claim_block(RayClaim& c, uint32_t* __restrict__ cursors, uint32_t n, uint32_t lane) {
+    const uint32_t seg_len = (((n + 7u) / 8u) + PT_RAY_BLOCK - 1u) / PT_RAY_BLOCK * PT_RAY_BLOCK;
+    while (!c.exhausted) {
+        uint32_t off = 0;
+        if (lane == 0) off = atomicAdd(cursors + c.seg * kCursorStride, static_cast<uint32_t>(PT_RAY_BLOCK));
+        off = __builtin_amdgcn_readfirstlane(off);
+        const uint64_t seg_first = static_cast<uint64_t>(c.seg) * seg_len;
+        const uint64_t seg_end = (seg_first + seg_len < n) ? seg_first + seg_len : n;
+        if (off < seg_len && seg_first + off < seg_end) {
+            c.next = static_cast<uint32_t>(seg_first + off);
+            c.end = static_cast<uint32_t>((seg_first + off + PT_RAY_BLOCK < seg_end) ? seg_first + off + PT_RAY_BLOCK : seg_end);
+            return;
+        }
+        c.seg = (c.seg + 1u) & 7u;
+        if (++c.tried == 8u) c.exhausted = true;
+    }
+    c.next = c.end = 0;
+}
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                       const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
@@ -415,7 +450,8 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                                                  const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                  float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                  uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
-                                                 uint32_t* __restrict__ next_ray, TraceCounters* counters) {
+                                                 uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
+                                                 TraceCounters* counters) {
     __shared__ uint32_t s_stack[kStackLds][kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -437,8 +473,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     uint32_t h_tri = 0;
     bool h_hit = false, h_back = false;
     int sp = 0;
-    bool exhausted = false;      // wave-uniform: the global cursor has passed n
-    uint32_t local_next = 0, local_end = 0;  // wave-uniform: block of rays owned by this wavefront
+    RayClaim claim = make_claim();
 
     auto is_node = [](uint32_t c) { return static_cast<int32_t>(c) >= 0; };
     auto is_leaf = [](uint32_t c) { return static_cast<int32_t>(c) < -2; };
@@ -472,7 +507,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                 cnt.census[phase][5] += n_leaf * steps;
             }
         };
-        const uint32_t n_wait = n_next + (exhausted ? 0u : n_idle);  // lanes that a service pass can move on
+        const uint32_t n_wait = n_next + (claim.exhausted ? 0u : n_idle);  // lanes that a service pass can move on
         if (n_wait && (n_wait >= PT_SERVICE_MIN || (n_inner + n_leaf) == 0u)) {
             // ================= service: finish instances, hand out rays, enter instances =================
             // One pass serves every lane that is not traversing, so a lane waits once between two instances
@@ -503,52 +538,42 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     }
                 }
                 const bool any_hit = (flags & F_ANY) != 0;
+                bool deferred = false;
                 if (!(any_hit && (flags & F_BHIT))) {
-                    uint2 e;
                     if (cursor < kCandMax) {
-                        e = cand.e[static_cast<size_t>(cursor) * cand.stride + rid];
-                    } else {  // more than kCandMax candidate instances along this ray: continue by rescanning
-                        const uint2 last = cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid];
-                        e = tlas_rescan(sc, ow, dw, any_hit, __uint_as_float(last.x), last.y);
-                        if (e.y != PT_NO_NODE) cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid] = e;
+                        const uint2 e = cand.e[static_cast<size_t>(cursor) * cand.stride + rid];
+                        ++cursor;
+                        if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) enter_slot = e.y;
+                    } else {
+                        deferred = true;  // all stored candidates are used up: the continuation pass takes the ray
                     }
-                    ++cursor;
-                    if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) enter_slot = e.y;
                 }
-                if (enter_slot == PT_NO_NODE) {  // the ray is done
+                if (enter_slot == PT_NO_NODE) {  // the ray is done here
                     if (!(flags & F_BHIT)) {
                         hit0[rid] = make_float4(kInfF, 0.0f, 0.0f, 0.0f);
                         hit1[rid] = 0u;
                     }
+                    if (deferred) overflow[1u + atomicAdd(overflow, 1u)] = rid;
                     cur = PT_IDLE;
                 }
             };
             if (cur == PT_NO_NODE) pick(false);
             bool fresh = false;
-            if (!exhausted) {
-                // The wavefront owns a block of PT_RAY_BLOCK consecutive rays claimed with ONE atomic on the global
-                // cursor (a single word sustains well under 100 M atomics/s, far less than the ray rate).
+            if (!claim.exhausted) {
                 const unsigned long long m_free = __ballot(cur == PT_IDLE);
                 const uint32_t n_free = __popcll(m_free);
-                if (n_free && local_next >= local_end) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(next_ray, static_cast<uint32_t>(PT_RAY_BLOCK));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    local_next = base;
-                    local_end = (base < n) ? ((n - base < PT_RAY_BLOCK) ? n : base + PT_RAY_BLOCK) : base;
-                    if (base >= n) exhausted = true;
-                }
-                const uint32_t avail = local_end - local_next;
+                if (n_free && claim.next >= claim.end) claim_block(claim, next_ray, n, lane);
+                const uint32_t avail = claim.end - claim.next;
                 const uint32_t rank = __popcll(m_free & lt_mask);
                 if (cur == PT_IDLE && rank < avail) {
-                    rid = local_next + rank;
+                    rid = claim.next + rank;
                     cursor = 0;
                     flags = 0;
                     b_t = kInfF;
                     h_hit = false;
                     fresh = true;
                 }
-                local_next += (n_free < avail) ? n_free : avail;
+                claim.next += (n_free < avail) ? n_free : avail;
             }
             if (fresh) pick(true);
             if (enter_slot != PT_NO_NODE) {
@@ -653,6 +678,57 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     }
 }
 
+// Continuation for rays with more than kCandMax candidate instances (a rarity: that many bounding volumes pierced
+// before the nearest hit).  The persistent kernels leave such a ray's record as it stands after its kCandMax-th
+// instance and list it; here the remaining instances are found by rescanning the DOPs in the same visiting order and
+// traced one ray per lane.  Keeping this out of the persistent kernels keeps a function call out of their loop.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void extend_overflow_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                                 const float4* __restrict__ ray_d, CandQueue cand,
+                                                                 const uint32_t* __restrict__ overflow,
+                                                                 float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                                                 uint32_t* __restrict__ spill, uint32_t spill_depth,
+                                                                 uint32_t spill_stride, TraceCounters* counters) {
+    __shared__ uint32_t s_stack[kStackLds][kBlock];
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t count = overflow[0];
+    TraceCount cnt{};
+    for (uint32_t i = gid; i < count; i += gridDim.x * kBlock) {
+        const uint32_t rid = overflow[1u + i];
+        const float4 ro = ray_o[rid], rd = ray_d[rid];
+        const f3 o = ld3(ro), d = ld3(rd);
+        const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
+        const float4 h0 = hit0[rid];
+        const uint32_t h1 = hit1[rid];
+        LaneHit best;
+        best.hit = (h1 & 0x80000000u) != 0;
+        best.t = best.hit ? h0.x : kInfF;
+        best.A = h0.y; best.B = h0.z; best.tri = __float_as_uint(h0.w);
+        best.object = h1 & 0x3fffffffu;
+        best.backface = (h1 & 0x40000000u) != 0;
+        uint2 last = cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid];
+        for (;;) {
+            const uint2 e = tlas_rescan(sc, o, d, any_hit, __uint_as_float(last.x), last.y);
+            if (e.y == PT_NO_NODE) break;
+            if (!any_hit && !(__uint_as_float(e.x) < best.t)) break;
+            if (COUNT) ++cnt.inst_entered;
+            if (any_hit) trace_instance<true, COUNT>(sc, e.y, o, d, best, s_stack, spill, spill_depth, spill_stride, gid, cnt);
+            else trace_instance<false, COUNT>(sc, e.y, o, d, best, s_stack, spill, spill_depth, spill_stride, gid, cnt);
+            if (any_hit && best.hit) break;
+            last = e;
+        }
+        hit0[rid] = make_float4(best.t, best.A, best.B, __uint_as_float(best.tri));
+        hit1[rid] = best.hit ? (best.object | (best.backface ? 0x40000000u : 0u) | 0x80000000u) : 0u;
+    }
+    if (COUNT) {
+        atomicAdd(&counters->nodes, static_cast<unsigned long long>(cnt.nodes));
+        atomicAdd(&counters->tris, static_cast<unsigned long long>(cnt.tris));
+        atomicAdd(&counters->inst_entered, static_cast<unsigned long long>(cnt.inst_entered));
+        atomicAdd(&counters->wave_inner, static_cast<unsigned long long>(cnt.wave_inner));
+        atomicAdd(&counters->wave_tri, static_cast<unsigned long long>(cnt.wave_tri));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // generate
 // ---------------------------------------------------------------------------------------------
@@ -682,17 +758,29 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t*
 __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const float2* __restrict__ sub,
                                                           uint32_t sample_begin, uint32_t sample_step,
                                                           uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
-                                                          RayQueue out, uint32_t* __restrict__ out_count) {
+                                                          uint32_t slots_in_batch, RayQueue out,
+                                                          uint32_t* __restrict__ out_count) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool valid = false;
     float4 o4, d4, p4;
     if (i < n) {
-        const uint64_t g = first + i;
         const uint32_t n_tiles = static_cast<uint32_t>(cam.tiles_x) * cam.tiles_y;
-        const uint32_t lane = static_cast<uint32_t>(g & 63u);
-        const uint64_t tile_lin = g >> 6;
-        const uint32_t tile = static_cast<uint32_t>(tile_lin % n_tiles);
-        const uint32_t slot = static_cast<uint32_t>(tile_lin / n_tiles);
+        uint32_t lane, tile, slot;
+        if (slots_in_batch) {
+            // batch = sample slots [first, first + slots_in_batch) of every tile, TILE-major: all samples of a tile
+            // are neighbours in the queue, so a contiguous part of the queue is a compact part of the screen
+            const uint32_t per_tile = slots_in_batch * 64u;
+            tile = i / per_tile;
+            const uint32_t rem = i - tile * per_tile;
+            slot = static_cast<uint32_t>(first) + (rem >> 6);
+            lane = rem & 63u;
+        } else {  // linear sample-major index (slot * n_tiles + tile) * 64 + lane, starting at `first`
+            const uint64_t g = first + i;
+            lane = static_cast<uint32_t>(g & 63u);
+            const uint64_t tile_lin = g >> 6;
+            tile = static_cast<uint32_t>(tile_lin % n_tiles);
+            slot = static_cast<uint32_t>(tile_lin / n_tiles);
+        }
         const uint32_t sample = sample_begin + slot * sample_step;
         const int x = static_cast<int>((tile % cam.tiles_x) * kTile + (lane & 7u));
         const int y = static_cast<int>((tile / cam.tiles_x) * kTile + (lane >> 3));
@@ -1231,11 +1319,11 @@ inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + kBloc
 }  // namespace
 
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
-                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n, RayQueue out,
-                     uint32_t* out_count) {
+                     uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
+                     uint32_t slots_in_batch, RayQueue out, uint32_t* out_count) {
     if (!n) return;
     hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
-                       sample_step, max_bounces, seed, first, n, out, out_count);
+                       sample_step, max_bounces, seed, first, n, slots_in_batch, out, out_count);
 }
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters) {
@@ -1255,22 +1343,29 @@ uint32_t extend_persistent_grid(int device) {
     return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(cus);
 }
 void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, CandQueue cand,
-                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray,
+                              uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray, uint32_t* overflow,
                               TraceCounters* counters, hipEvent_t between) {
     if (!n) return;
     const uint32_t grid = std::min<uint32_t>(n_blocks, blocks_for(n));
     const uint32_t stride = n_blocks * kBlock;  // one spill column per persistent thread
-    (void)hipMemsetAsync(next_ray, 0, sizeof(uint32_t), st);
+    (void)hipMemsetAsync(next_ray, 0, 8 * kCursorStride * sizeof(uint32_t), st);
+    (void)hipMemsetAsync(overflow, 0, sizeof(uint32_t), st);
+    const dim3 g_all(blocks_for(n)), g_p(grid), g_c(std::min<uint32_t>(n_blocks, 64u)), b(kBlock);
     if (counters) {
-        hipLaunchKernelGGL(tlas_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        hipLaunchKernelGGL(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        hipLaunchKernelGGL(traverse_kernel<true>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
-                           hits.h1, spill, spill_depth, stride, next_ray, counters);
+        hipLaunchKernelGGL(traverse_kernel<true>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                           spill_depth, stride, next_ray, overflow, counters);
+        hipLaunchKernelGGL(extend_overflow_kernel<true>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
+                           spill_depth, stride, counters);
     } else {
-        hipLaunchKernelGGL(tlas_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, counters);
+        hipLaunchKernelGGL(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        hipLaunchKernelGGL(traverse_kernel<false>, dim3(grid), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, cand, hits.h0,
-                           hits.h1, spill, spill_depth, stride, next_ray, counters);
+        hipLaunchKernelGGL(traverse_kernel<false>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                           spill_depth, stride, next_ray, overflow, counters);
+        // continuation of the rare rays with more candidate instances than the lists hold (returns at once when none)
+        hipLaunchKernelGGL(extend_overflow_kernel<false>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
+                           spill_depth, stride, counters);
     }
 }
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,

