@@ -33,7 +33,12 @@ def combine_partial_sums(buf: torch.Tensor, total_spp: int, rank: int, world: in
     """Reduce the (H, W, 4) partial-sum buffers of all ranks onto rank 0 and turn the sum into the mean
     image there (rgb / total_spp, alpha 1).  Returns the image on rank 0, None elsewhere."""
     if world > 1:
-        dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
+        if buf.is_cuda and dist.get_backend() == "gloo":  # gloo reduces host tensors only (rehearsals without RCCL)
+            host = buf.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
+        else:
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM)
     if rank != 0:
         return None
     if resolve is not None:
