@@ -820,6 +820,7 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
 // textures and materials (cpu_framebuffer.h:35-50, 90-123; brdf.cc:11-69)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wrap_coord(int v, int n) {  // ((v % n) + n) % n
+    if ((n & (n - 1)) == 0) return v & (n - 1);  // power-of-two sizes: the same value without an integer division
     int r = v % n;
     return (r < 0) ? r + n : r;
 }
@@ -836,23 +837,28 @@ __device__ __forceinline__ Taps bilinear_taps(float u, float v, int w, int h) {
     int x0 = static_cast<int>(fx), y0 = static_cast<int>(fy);
     t.x0 = wrap_coord(x0, w);
     t.y0 = wrap_coord(y0, h);
-    t.x1 = wrap_coord(x0 + 1, w);
-    t.y1 = wrap_coord(y0 + 1, h);
+    // wrap(x0 + 1) follows from wrap(x0): the next texel of the row, or texel 0 after the last one
+    t.x1 = (t.x0 + 1 == w) ? 0 : t.x0 + 1;
+    t.y1 = (t.y0 + 1 == h) ? 0 : t.y0 + 1;
     return t;
 }
 // The sRGB decode table (256 floats) is copied to LDS by every shading workgroup: a texture sample decodes twelve
 // channels, and as global gathers those would be half of the kernel's vector memory instructions.
+// Its neighbour holds i / 255 (the linear decode and every alpha channel): a table read instead of an IEEE division per
+// channel, the same binary32 value.
 __shared__ float s_srgb_lut[256];
-__device__ __forceinline__ void stage_srgb_lut(const SceneDev& sc) {
+__shared__ float s_unorm_lut[256];
+__device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
     static_assert(kBlock == 256, "one table entry per thread");
     s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+    s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
     __syncthreads();
 }
 __device__ __forceinline__ float4 texel8(const SceneDev& sc, uint32_t word, bool srgb) {
     uint32_t r = word & 0xffu, g = (word >> 8) & 0xffu, b = (word >> 16) & 0xffu, a = word >> 24;
-    float fa = static_cast<float>(a) / 255.0f;
+    const float fa = s_unorm_lut[a];
     if (srgb) return make_float4(s_srgb_lut[r], s_srgb_lut[g], s_srgb_lut[b], fa);
-    return make_float4(static_cast<float>(r) / 255.0f, static_cast<float>(g) / 255.0f, static_cast<float>(b) / 255.0f, fa);
+    return make_float4(s_unorm_lut[r], s_unorm_lut[g], s_unorm_lut[b], fa);
 }
 __device__ __forceinline__ float4 sample_image(const SceneDev& sc, const DevTexture& im, float u, float v, bool srgb) {
     const Taps t = bilinear_taps(u, v, im.width, im.height);
@@ -1039,7 +1045,7 @@ __device__ __forceinline__ void add_radiance(FrameDev fb, uint32_t pid, f3 c) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                                FrameDev fb) {
-    stage_srgb_lut(sc);
+    stage_decode_tables(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 ro = rays.o[i], rd = rays.d[i];
@@ -1067,6 +1073,7 @@ __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQ
 __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                           RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb,
                                                           uint32_t ao_samples) {
+    stage_decode_tables(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool spawn = false;
     f3 new_pos = mk3(0.0f);
@@ -1135,7 +1142,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 #endif
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
-    stage_srgb_lut(sc);
+    stage_decode_tables(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
     float4 no[4], nd[4], np[4];
