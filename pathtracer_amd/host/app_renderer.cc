@@ -225,12 +225,27 @@ void CPUFrameBuffer::save_to_file(const std::filesystem::path& filePath) const {
 // ---------------------------------------------------------------------------------------------
 // scene container reader
 // ---------------------------------------------------------------------------------------------
+Model load_gltf_model(const std::filesystem::path& path);  // gltf_loader.cc
+
 bool ModelLoader::loadFromFile(std::filesystem::path path) {
+    if (!std::filesystem::exists(path)) {
+        std::fprintf(stdout, "Failed to find \"%s\"\n", path.string().c_str());
+        return false;
+    }
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
-    char magic[8];
+    char magic[8] = {};
+    f.read(magic, 8);
+    if (std::memcmp(magic, "PTSC0001", 8) != 0) {  // glTF 2.0: binary container or JSON text
+        try {
+            model_ = load_gltf_model(path);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return false;
+        }
+        return true;
+    }
     uint64_t n[8];
-    if (!f.read(magic, 8) || std::memcmp(magic, "PTSC0001", 8) != 0) return false;
     if (!f.read(reinterpret_cast<char*>(n), sizeof(n))) return false;
     const uint64_t nv = n[0], ni = n[1], nm = n[2], no = n[3], nmat = n[4], nimg = n[5], ntex = n[6], ncam = n[7];
     std::vector<ptgpu_vertex> vertices(nv);
@@ -308,6 +323,66 @@ bool ModelLoader::loadFromFile(std::filesystem::path path) {
     }
     model_ = std::move(m);
     return true;
+}
+
+bool save_scene_container(const Model& m, const std::filesystem::path& path) {
+    std::vector<ptgpu_vertex> vertices;
+    std::vector<uint32_t> indices;
+    std::vector<ptgpu_mesh> meshes;
+    for (const Mesh& s : m.meshes_) {
+        meshes.push_back({static_cast<uint32_t>(vertices.size()), static_cast<uint32_t>(s.vertices.size()), static_cast<uint32_t>(indices.size()),
+                          static_cast<uint32_t>(s.indices.size()), s.materialIndex});
+        const size_t v0 = vertices.size();
+        vertices.resize(v0 + s.vertices.size());
+        std::memcpy(static_cast<void*>(vertices.data() + v0), s.vertices.data(), s.vertices.size() * sizeof(vertex));
+        indices.insert(indices.end(), s.indices.begin(), s.indices.end());
+    }
+    std::vector<ptgpu_object> objects(m.objects_.size());
+    for (size_t i = 0; i < objects.size(); ++i) {
+        std::memcpy(objects[i].model_matrix, &m.objects_[i].ModelMatrix, 64);
+        std::memcpy(objects[i].normal_matrix, &m.objects_[i].NormalMatrix, 64);
+        objects[i].mesh_index = m.objects_[i].meshIndex;
+    }
+    std::vector<ptgpu_material> materials(m.materials_.size());
+    for (size_t i = 0; i < materials.size(); ++i) {
+        const Material& s = m.materials_[i];
+        ptgpu_material& d = materials[i];
+        std::memcpy(d.base_color_factor, &s.baseColorFactor, 16);
+        std::memcpy(d.emissive_factor, &s.emissiveFactor, 12);
+        std::memcpy(d.attenuation_factor, &s.attenuationFactor, 12);
+        d.metallic_factor = s.metallicFactor; d.roughness_factor = s.roughnessFactor;
+        d.base_color_texture = s.baseColorTextureIndex; d.metallic_roughness_texture = s.metallicRoughnessTextureIndex;
+        d.normal_texture = s.normalTextureIndex; d.ior = s.ior; d.dielectric_f0 = s.dielectric_f0;
+        d.transmission_factor = s.transmisionFactor; d.transmission_texture = s.transmissionTextureIndex;
+        d.emissive_texture = s.emissiveTextureIndex; d.emissive_strength = s.emissiveStrength;
+        d.double_sided = s.doubleSided; d.has_volume = s.hasVolume; d.alpha_blending = s.alphaBlending; d.alpha_cutoff = s.alpha_cutoff;
+    }
+    std::vector<ptgpu_image> images;
+    std::vector<sdr_pixel> texels;
+    for (const CPUTexture<sdr_pixel>& t : m.images_) {
+        images.push_back({t.width(), t.height(), texels.size()});
+        texels.insert(texels.end(), t.data(), t.data() + static_cast<size_t>(t.width()) * t.height());
+    }
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    const uint64_t n[8] = {vertices.size(), indices.size(), meshes.size(), objects.size(), materials.size(), images.size(), texels.size(), m.cameras_.size()};
+    f.write("PTSC0001", 8);
+    f.write(reinterpret_cast<const char*>(n), sizeof(n));
+    auto wr = [&](const void* p, size_t bytes) { if (bytes) f.write(static_cast<const char*>(p), static_cast<std::streamsize>(bytes)); };
+    wr(vertices.data(), vertices.size() * sizeof(ptgpu_vertex));
+    wr(indices.data(), indices.size() * 4);
+    wr(meshes.data(), meshes.size() * sizeof(ptgpu_mesh));
+    wr(objects.data(), objects.size() * sizeof(ptgpu_object));
+    wr(materials.data(), materials.size() * sizeof(ptgpu_material));
+    wr(images.data(), images.size() * sizeof(ptgpu_image));
+    wr(texels.data(), texels.size() * 4);
+    for (const Camera& c : m.cameras_) {  // position, direction, up as the viewer reads them (src/viewer.cc:61-63)
+        const float v[12] = {c.ModelMatrix[3].x, c.ModelMatrix[3].y, c.ModelMatrix[3].z, -c.ModelMatrix[2].x, -c.ModelMatrix[2].y, -c.ModelMatrix[2].z,
+                             c.ModelMatrix[1].x, c.ModelMatrix[1].y, c.ModelMatrix[1].z, c.camera_params.yfov, c.camera_params.znear,
+                             c.camera_params.zfar.value_or(1000.0f)};
+        wr(v, sizeof(v));
+    }
+    return static_cast<bool>(f);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // PathTracer — command line of the reference (src/main.cc:12-62, src/arguments.cc:28-147) above the GPU renderer.
-// Same flags, defaults, stdout lines and exit codes; -f takes the flat scene container ("PTSC0001") until a glTF
-// reader exists.  Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw
-// ptgpu_hit records, row-major) and --stats.
+// Same flags, defaults, stdout lines and exit codes; -f takes glTF 2.0 (.glb / .gltf) or the flat scene container.
+// Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw ptgpu_hit records,
+// row-major) and --stats.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@ struct Args {
 };
 
 const char* kUsage =
-    "Usage: PathTracer -f <scene.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2]\n"
+    "Usage: PathTracer -f <scene.glb|.gltf|.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2]\n"
     "                  [-s samples] [-b bounces] [-r newrays] [--env_rot degrees] [-m max_leaf_triangles]\n"
     "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats]\n"
     "Use -h or --help for usage info.\n";

@@ -202,7 +202,9 @@ class ModelBuilder:
         default_idx = len(mats)
         mb = ModelBuilder()
         mb.add_material()
-        mats.append(mb._materials[0])
+        default = dict(mb._materials[0])
+        default["dielectric_f0"] = np.float32(0.04)  # the literal of Material{} (model_loader.h:44), not f0_dielectric(1.5)
+        mats.append(default)
         materials = np.zeros(len(mats), abi.MATERIAL_DTYPE)
         for i, m in enumerate(mats):
             for k, val in m.items():

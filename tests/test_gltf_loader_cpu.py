@@ -1,0 +1,185 @@
+"""The C++ glTF reader and image decoders of the host (the reference's ModelLoader, src/model_loader.cc:17-214, and
+the stb decoding behind CPUTexture<sdr_pixel>, src/cpu_framebuffer.cc:36-83), driven through libptapp.so's C entry
+points.  No GPU needed.  Pillow provides independent encoders/decoders to compare with."""
+import ctypes as C
+import io
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pathtracer_amd import gltf_export, scenes
+from pathtracer_amd.model import SceneModel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "pathtracer_amd", "lib", "libptapp.so")
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB), reason="C++ host not built (run __graft_entry__.build())")
+PIL = pytest.importorskip("PIL.Image")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import pathtracer_amd._lib  # noqa: F401  (loads libptgpu.so, which libptapp.so depends on, from the same directory)
+    L = C.CDLL(LIB)
+    L.ptapp_convert_scene.restype = C.c_int
+    L.ptapp_convert_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+    L.ptapp_decode_image.restype = C.c_int
+    L.ptapp_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    return L
+
+
+def decode(lib, data: bytes):
+    w, h, ch = C.c_int(), C.c_int(), C.c_int()
+    err = C.create_string_buffer(256)
+    if lib.ptapp_decode_image(data, len(data), w, h, ch, None, 0, err, 256):
+        raise RuntimeError(err.value.decode())
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    assert lib.ptapp_decode_image(data, len(data), w, h, ch, out.ctypes.data, out.nbytes, err, 256) == 0
+    return out, ch.value
+
+
+def encoded(img, fmt, **kw):
+    b = io.BytesIO()
+    img.save(b, fmt, **kw)
+    return b.getvalue()
+
+
+def test_png_decoding_matches_pillow(lib):
+    rng = np.random.default_rng(1)
+    rgba = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    for mode, arr in (("RGBA", rgba), ("RGB", rgba[..., :3]), ("L", rgba[..., 0]), ("LA", rgba[..., [0, 3]])):
+        img = PIL.fromarray(np.ascontiguousarray(arr), mode)
+        got, ch = decode(lib, encoded(img, "PNG"))
+        assert np.array_equal(got, np.asarray(img.convert("RGBA"))), mode
+        assert ch == len(mode)
+    pal = PIL.fromarray(rgba[..., :3], "RGB").quantize(colors=13)  # palette image with 4-bit indices
+    got, _ = decode(lib, encoded(pal, "PNG", bits=4))
+    assert np.array_equal(got, np.asarray(pal.convert("RGBA")))
+    one = PIL.fromarray((rgba[..., 0] > 127).astype(np.uint8) * 255, "L").convert("1")  # 1-bit gray
+    got, _ = decode(lib, encoded(one, "PNG"))
+    assert np.array_equal(got, np.asarray(one.convert("RGBA")))
+    g16 = rng.integers(0, 65536, (9, 11), dtype=np.uint16)  # 16-bit gray keeps its high byte
+    got, _ = decode(lib, encoded(PIL.fromarray(g16), "PNG"))
+    assert np.array_equal(got[..., 0], (g16 >> 8).astype(np.uint8)) and (got[..., 3] == 255).all()
+    with pytest.raises(RuntimeError, match="neither PNG nor JPEG"):
+        decode(lib, b"GIF89a" + bytes(32))
+    with pytest.raises(RuntimeError, match="Unable to load image from memory"):
+        decode(lib, encoded(PIL.fromarray(rgba, "RGBA"), "PNG")[:200])
+
+
+def test_baseline_jpeg_decoding_close_to_pillow(lib):
+    y, x = np.mgrid[0:96, 0:120]
+    smooth = np.stack([127 + 100 * np.sin(x / 17.0), 127 + 90 * np.cos(y / 11.0), 60 + (x + y) * 0.8], -1)
+    smooth = np.clip(smooth, 0, 255).astype(np.uint8)
+    for sub, kw in ((0, {}), (2, {}), (1, {}), (2, {"restart_marker_blocks": 3})):
+        data = encoded(PIL.fromarray(smooth, "RGB"), "JPEG", quality=92, subsampling=sub, **kw)
+        got, ch = decode(lib, data)
+        ref = np.asarray(PIL.open(io.BytesIO(data)).convert("RGBA")).astype(np.int32)
+        d = np.abs(got.astype(np.int32) - ref)
+        assert ch == 3 and d.max() <= 8 and d.mean() < 1.0, (sub, kw, d.max(), d.mean())
+    gray = encoded(PIL.fromarray(smooth[..., 0], "L"), "JPEG", quality=90)
+    got, ch = decode(lib, gray)
+    ref = np.asarray(PIL.open(io.BytesIO(gray)).convert("RGBA")).astype(np.int32)
+    assert ch == 1 and np.abs(got.astype(np.int32) - ref).max() <= 2
+    prog = encoded(PIL.fromarray(smooth, "RGB"), "JPEG", progressive=True)
+    with pytest.raises(RuntimeError, match="progressive"):
+        decode(lib, prog)
+
+
+def convert(lib, src, dst):
+    err = C.create_string_buffer(512)
+    rc = lib.ptapp_convert_scene(str(src).encode(), str(dst).encode(), err, 512)
+    if rc:
+        raise RuntimeError(err.value.decode())
+    return SceneModel.load(str(dst))
+
+
+def test_glb_round_trip(lib, tmp_path):
+    model = scenes.tiny_scene()
+    gltf_export.save_glb(model, str(tmp_path / "tiny.glb"))
+    back = convert(lib, tmp_path / "tiny.glb", tmp_path / "tiny.ptsc")
+    assert np.array_equal(back.vertices, model.vertices) and np.array_equal(back.indices, model.indices)
+    assert np.array_equal(back.meshes, model.meshes)
+    assert np.array_equal(back.images, model.images) and np.array_equal(back.texels, model.texels)
+    assert np.array_equal(back.objects["mesh_index"], model.objects["mesh_index"])
+    assert np.array_equal(back.objects["model_matrix"], model.objects["model_matrix"])
+    assert np.allclose(back.objects["normal_matrix"], model.objects["normal_matrix"], rtol=2e-5, atol=1e-6)
+    assert len(back.materials) == len(model.materials)  # the default material is appended by the reader again
+    for name in model.materials.dtype.names:
+        a, b = back.materials[name], model.materials[name]
+        if name == "attenuation_factor":
+            assert np.allclose(a, b, rtol=1e-6, atol=1e-7)
+        else:
+            assert np.array_equal(a, b), name
+    assert len(back.cameras) == len(model.cameras) == 1
+    for f in ("position", "direction", "up"):
+        assert np.allclose(getattr(back.cameras[0], f), getattr(model.cameras[0], f), atol=1e-6)
+    assert back.cameras[0].yfov == pytest.approx(model.cameras[0].yfov, rel=1e-6)
+
+
+def _minimal_gltf(tmp_path, prim_extra=None, node=None, material=None, mode=None):
+    """A .gltf (JSON + external .bin) holding one triangle pair without indices, uv, tangents or material."""
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (6, 1))
+    uv16 = (np.array([[0, 0], [1, 0], [0, 1], [1, 0], [1, 1], [0, 1]], np.float32) * 65535).astype(np.uint16)
+    blob = pos.tobytes() + nrm.tobytes() + uv16.tobytes()
+    (tmp_path / "geo.bin").write_bytes(blob)
+    prim = {"attributes": {"POSITION": 0, "NORMAL": 1}}
+    if prim_extra:
+        prim["attributes"].update(prim_extra)
+    if mode is not None:
+        prim["mode"] = mode
+    doc = {"asset": {"version": "2.0"}, "buffers": [{"uri": "geo.bin", "byteLength": len(blob)}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 72}, {"buffer": 0, "byteOffset": 72, "byteLength": 72},
+                           {"buffer": 0, "byteOffset": 144, "byteLength": 24}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 6, "type": "VEC3"},
+                         {"bufferView": 1, "componentType": 5126, "count": 6, "type": "VEC3"},
+                         {"bufferView": 2, "componentType": 5123, "normalized": True, "count": 6, "type": "VEC2"}],
+           "meshes": [{"primitives": [prim, dict(prim)]}],
+           "nodes": [{"children": [1], "translation": [1, 2, 3]}, node or {"mesh": 0, "scale": [2, 2, 2]}],
+           "scenes": [{"nodes": [0]}]}
+    if material:
+        doc["materials"] = [material]
+        doc["meshes"][0]["primitives"][0]["material"] = 0
+    (tmp_path / "m.gltf").write_text(json.dumps(doc))
+    return tmp_path / "m.gltf"
+
+
+def test_gltf_defaults_and_hierarchy(lib, tmp_path):
+    src = _minimal_gltf(tmp_path, material={"extensions": {"KHR_materials_volume": {"attenuationColor": [0.5, 1.0, 0.0]},
+                                                           "KHR_materials_ior": {"ior": 1.33}}})
+    m = convert(lib, src, tmp_path / "m.ptsc")
+    assert len(m.meshes) == 2 and len(m.objects) == 2              # one Mesh per primitive, one Object per primitive of the node
+    assert np.array_equal(m.indices, np.tile(np.arange(6, dtype=np.uint32), 2))   # GenerateMeshIndices
+    assert len(m.materials) == 2 and m.meshes["material_index"].tolist() == [0, 1]  # second primitive -> default material
+    assert (m.vertices["uv"] == 0).all()                           # no TEXCOORD_0
+    # no uv: tangent = cross(normal, +Y), w = 1 (compute_tangents.cc:64-70)
+    assert np.allclose(m.vertices["tangent"], [[-1, 0, 0, 1]])
+    mat = m.materials[0]
+    assert mat["has_volume"] == 1 and np.allclose(mat["attenuation_factor"], [0.0, 0.0, 0.0])  # infinite distance by default
+    assert mat["ior"] == np.float32(1.33) and mat["dielectric_f0"] == pytest.approx(((1.33 - 1) / (1.33 + 1)) ** 2, rel=1e-6)
+    assert mat["alpha_cutoff"] == -1.0 and mat["metallic_factor"] == 1.0 and mat["base_color_texture"] == -1
+    dm = m.materials[1]                                             # Material{} defaults (model_loader.h:33-52)
+    assert dm["ior"] == 1.5 and dm["dielectric_f0"] == np.float32(0.04) and dm["roughness_factor"] == 1.0
+    world = m.objects["model_matrix"][0].reshape(4, 4).T            # parent translation x child scale
+    assert np.allclose(world, [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, 2, 3], [0, 0, 0, 1]])
+    nm = m.objects["normal_matrix"][0].reshape(4, 4).T
+    assert np.allclose(nm, np.linalg.inv(world).T, atol=1e-6)
+    # normalised 16-bit uv and generated tangents
+    m = convert(lib, _minimal_gltf(tmp_path, prim_extra={"TEXCOORD_0": 2}), tmp_path / "m2.ptsc")
+    assert np.allclose(m.vertices["uv"][:6], [[0, 0], [1, 0], [0, 1], [1, 0], [1, 1], [0, 1]])
+    assert np.allclose(m.vertices["tangent"], [[1, 0, 0, 1]], atol=1e-6)
+
+
+def test_gltf_errors(lib, tmp_path):
+    with pytest.raises(RuntimeError, match="loadFromFile failed"):
+        convert(lib, tmp_path / "missing.glb", tmp_path / "x.ptsc")
+    with pytest.raises(RuntimeError, match="loadFromFile failed"):
+        convert(lib, _minimal_gltf(tmp_path, mode=1), tmp_path / "x.ptsc")   # line primitives
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"glTF" + struct.pack("<II", 2, 1000) + b"\0" * 20)
+    with pytest.raises(RuntimeError, match="loadFromFile failed"):
+        convert(lib, bad, tmp_path / "x.ptsc")

@@ -101,3 +101,22 @@ def test_cli_matches_python_mirror(tmp_path):
     scale = np.maximum(img[..., :3].max(axis=-1, keepdims=True), 1e-6)
     assert np.abs(got[..., :3] - img[..., :3]).max() <= (scale / 100.0).max()
     assert (np.abs(got[..., :3] - img[..., :3]) <= scale / 100.0).all()
+
+
+@needs_cli
+@pytest.mark.gpu
+def test_cli_renders_glb_like_the_scene_container(tmp_path):
+    """-f scene.glb goes through the C++ glTF reader; the same scene as a flat container must give the same picture
+    (normal matrices are recomputed in binary32 by the reader, hence a tolerance instead of equality)."""
+    from pathtracer_amd import gltf_export
+    model = scenes.tiny_scene()
+    model.save(str(tmp_path / "s.ptsc"))
+    gltf_export.save_glb(model, str(tmp_path / "s.glb"))
+    outs = {}
+    for ext in ("ptsc", "glb"):
+        out = tmp_path / f"{ext}.hdr"
+        r = run("-f", tmp_path / f"s.{ext}", "-p", 3, "-a", 2, "-s", 8, "-b", 3, "--width", 64, "--height", 40, "--seed", 5, "-o", out)
+        assert r.returncode == 0, r.stderr
+        outs[ext] = image_io.load_hdr(str(out))[..., :3]
+    diff = np.abs(outs["glb"] - outs["ptsc"])
+    assert diff.mean() < 2e-3 * max(1.0, outs["ptsc"].mean()) and np.median(diff) == 0.0
