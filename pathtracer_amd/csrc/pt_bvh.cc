@@ -5,9 +5,12 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace pth {
 namespace {
@@ -149,6 +152,58 @@ inline void fnv_u32(uint64_t& h, uint32_t v) {
     }
 }
 
+// A range of triangles waiting to become a subtree, and the slot of its parent that receives box and reference.
+struct Task {
+    uint32_t begin, end;
+    uint32_t parent;  // node index, or PT_NO_NODE for the root of this build
+    bool right;
+};
+
+// parse (:406-447) with an explicit work list: left ranges are processed before right ranges, so nodes are numbered
+// in depth-first order.  Ranges of at most `defer_below` triangles (when non-zero) are recorded in `deferred` with their
+// box already stored in the parent, instead of being expanded.
+void build_range(std::vector<ptd::DevTri>& tris, Task first, uint32_t max_leaf, std::vector<ptd::DevNode>& nodes, uint32_t* root,
+                 uint32_t defer_below, std::vector<Task>* deferred) {
+    std::vector<Task> work{first};
+    while (!work.empty()) {
+        const Task tk = work.back();
+        work.pop_back();
+        const Box box = range_box(tris.data() + tk.begin, tris.data() + tk.end);
+        const uint32_t count = tk.end - tk.begin;
+        uint32_t ref = PT_NO_NODE;
+        const bool defer = defer_below && deferred && tk.parent != PT_NO_NODE && count <= defer_below && count > max_leaf;
+        if (defer) {
+            deferred->push_back(tk);
+        } else {
+            uint32_t mid = tk.end;
+            if (count > max_leaf) mid = choose_split(tris, tk.begin, tk.end, box, max_leaf);
+            if (mid == tk.end) {
+                tris[tk.begin].leaf_count = count;
+                ref = PT_LEAF_BIT | tk.begin;
+            } else {
+                ref = static_cast<uint32_t>(nodes.size());
+                nodes.emplace_back();
+                work.push_back({mid, tk.end, ref, true});
+                work.push_back({tk.begin, mid, ref, false});
+            }
+        }
+        if (tk.parent == PT_NO_NODE) {
+            *root = ref;
+        } else {
+            ptd::DevNode& p = nodes[tk.parent];
+            if (tk.right) {
+                std::memcpy(p.r_lo, box.lo, 12);
+                std::memcpy(p.r_hi, box.hi, 12);
+                p.right = ref;
+            } else {
+                std::memcpy(p.l_lo, box.lo, 12);
+                std::memcpy(p.l_hi, box.hi, 12);
+                p.left = ref;
+            }
+        }
+    }
+}
+
 void collect_info(MeshTree& t, uint32_t n_real_tris) {  // collect_tree_info, :538-570
     ptgpu_bvh_info r{};
     r.min_depth = 0xffffffffu;
@@ -219,45 +274,43 @@ void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint
         collect_info(out, n_tris);
         return;
     }
-    // Top-down build with an explicit work list.  A task is a triangle range plus the slot of its
-    // parent that receives the finished child's box and reference; left ranges are processed before
-    // right ranges, so nodes are numbered in depth-first order.
-    struct Task {
-        uint32_t begin, end;
-        uint32_t parent;  // node index, or PT_NO_NODE for the root
-        bool right;
-    };
-    std::vector<Task> work{{0u, n_tris, PT_NO_NODE, false}};
-    while (!work.empty()) {
-        const Task tk = work.back();
-        work.pop_back();
-        const Box box = range_box(out.tris.data() + tk.begin, out.tris.data() + tk.end);  // parse, :406-447
-        uint32_t ref;
-        const uint32_t count = tk.end - tk.begin;
-        uint32_t mid = tk.end;
-        if (count > max_leaf) mid = choose_split(out.tris, tk.begin, tk.end, box, max_leaf);
-        if (mid == tk.end) {
-            out.tris[tk.begin].leaf_count = count;
-            ref = PT_LEAF_BIT | tk.begin;
-        } else {
-            ref = static_cast<uint32_t>(out.nodes.size());
-            out.nodes.emplace_back();
-            work.push_back({mid, tk.end, ref, true});
-            work.push_back({tk.begin, mid, ref, false});
-        }
-        if (tk.parent == PT_NO_NODE) {
-            out.root = ref;
-        } else {
-            ptd::DevNode& p = out.nodes[tk.parent];
-            if (tk.right) {
-                std::memcpy(p.r_lo, box.lo, 12);
-                std::memcpy(p.r_hi, box.hi, 12);
-                p.right = ref;
-            } else {
-                std::memcpy(p.l_lo, box.lo, 12);
-                std::memcpy(p.l_hi, box.hi, 12);
-                p.left = ref;
+    // Top-down build with an explicit work list (build_range).  Ranges of at most `defer_below` triangles are not
+    // expanded by the first, serial pass: they are independent subtrees (choose_split only permutes triangles inside
+    // its own range), built by a few threads into private node arrays and appended in left-to-right order.  The
+    // tree — boxes, split planes, triangle order, leaves — is the one a single-threaded build produces; only the
+    // numbering of the nodes differs (top part first, then the subtrees).
+    std::vector<Task> deferred;
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const char* env = std::getenv("PTGPU_BUILD_THREADS");
+    const unsigned n_threads = env ? static_cast<unsigned>(std::max(1, std::atoi(env))) : hw;
+    const uint32_t defer_below = (n_threads > 1 && n_tris >= (1u << 16)) ? std::max<uint32_t>(n_tris / (n_threads * 8u), max_leaf) : 0u;
+    build_range(out.tris, Task{0u, n_tris, PT_NO_NODE, false}, max_leaf, out.nodes, &out.root, defer_below, &deferred);
+    if (!deferred.empty()) {
+        struct Subtree {
+            std::vector<ptd::DevNode> nodes;
+            uint32_t root = 0;
+        };
+        std::vector<Subtree> subs(deferred.size());
+        std::atomic<size_t> next{0};
+        auto worker = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < deferred.size();)
+                build_range(out.tris, Task{deferred[i].begin, deferred[i].end, PT_NO_NODE, false}, max_leaf, subs[i].nodes, &subs[i].root, 0, nullptr);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);
+        worker();
+        for (std::thread& t : pool) t.join();
+        for (size_t i = 0; i < deferred.size(); ++i) {
+            const uint32_t base = static_cast<uint32_t>(out.nodes.size());
+            auto move = [base](uint32_t ref) { return (ref & PT_LEAF_BIT) ? ref : ref + base; };
+            for (ptd::DevNode n : subs[i].nodes) {
+                n.left = move(n.left);
+                n.right = move(n.right);
+                out.nodes.push_back(n);
             }
+            // the parent slot already holds the subtree's box (written by the serial pass); only the reference is open
+            ptd::DevNode& p = out.nodes[deferred[i].parent];
+            (deferred[i].right ? p.right : p.left) = move(subs[i].root);
         }
     }
     collect_info(out, n_tris);
