@@ -74,6 +74,8 @@ __device__ __forceinline__ float dop_forward_distance(const float* __restrict__ 
         tmin = (tmin < t0) ? t0 : tmin;  // std::max(t0, tmin)
         tmax = (t1 < tmax) ? t1 : tmax;  // std::min(t1, tmax)
         if (hit && (tmax < tmin)) hit = false;  // the reference returns here; later axes cannot un-miss
+        // after the three box slabs most misses are decided: leave when no lane of the wavefront is still inside
+        if (i == 2 && __ballot(hit) == 0ull) return kInfF;
     }
     return forward_distance(hit, tmin, tmax);
 }
@@ -391,6 +393,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
     const uint32_t n_inst = sc.n_instances;
     for (uint32_t k = 0; k < n_inst; ++k) {
         const float dist = dop_forward_distance(sc.instances[k].dop, pr);
+        if (__ballot(dist < kInfF) == 0ull) continue;  // no ray of this wavefront touches the instance: skip the insertion
         if (dist < kInfF) {
             // sorted insertion; strict '<' keeps table order among equal distances
             float ck = any_hit ? -static_cast<float>(k) : dist;
