@@ -143,6 +143,7 @@ struct ptgpu_ctx {
     // of the persistent extend kernel ends with a tail in which a few long rays keep nearly empty wavefronts
     // alive, so throughput grows with the launch size (about +18 % from 8 Mi to 64 Mi rays), and the memory is there.
     uint32_t chunk = 1u << 26;
+    uint32_t batch_cap = 0;        // camera samples per batch the ray pools are sized for
     uint32_t launch_cap = 0;       // rays per launch the work buffers are sized for (also the candidate list stride)
     Pool pools[2];
     DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand, overflow;
@@ -227,8 +228,10 @@ uint32_t fanout_of(const ptgpu_settings& s) {
     return 0;
 }
 
-int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t K) {
-    K = std::max<uint64_t>(K, c->launch_cap);
+// K = camera samples per batch (sizes the ray pools), L = largest launch (sizes hit records, candidate lists, overflow list)
+int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t K, uint64_t L) {
+    K = std::max<uint64_t>(K, c->batch_cap);
+    L = std::max<uint64_t>(std::max<uint64_t>(L, K), c->launch_cap);
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
@@ -242,22 +245,23 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
             p.cap = cap;
         }
     }
-    PT_HIP(c, c->hit0.ensure(K * 16));
-    PT_HIP(c, c->hit1.ensure(K * 4));
+    PT_HIP(c, c->hit0.ensure(L * 16));
+    PT_HIP(c, c->hit1.ensure(L * 4));
     const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
     if (c->persistent && !c->persist_blocks) {
         c->persist_blocks = ptd::extend_persistent_grid(c->device);
         if (const char* b = std::getenv("PTGPU_PERSIST_BLOCKS")) c->persist_blocks = static_cast<uint32_t>(std::max(1, std::atoi(b)));
         if (std::getenv("PTGPU_VERBOSE")) std::fprintf(stderr, "[ptgpu] persistent extend grid: %u workgroups\n", c->persist_blocks);
     }
-    const uint64_t spill_columns = c->persistent ? static_cast<uint64_t>(c->persist_blocks) * ptd::kBlock : K;
+    const uint64_t spill_columns = c->persistent ? static_cast<uint64_t>(c->persist_blocks) * ptd::kBlock : L;
     PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * spill_columns * 4 + 16));
     PT_HIP(c, c->ray_cursor.ensure(1024));
-    if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * K * sizeof(uint2)));
-    if (c->persistent) PT_HIP(c, c->overflow.ensure((K + 1) * sizeof(uint32_t)));
+    if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * L * sizeof(uint2)));
+    if (c->persistent) PT_HIP(c, c->overflow.ensure((L + 1) * sizeof(uint32_t)));
     PT_HIP(c, c->counter.ensure(16));
     PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
-    c->launch_cap = static_cast<uint32_t>(K);
+    c->batch_cap = static_cast<uint32_t>(K);
+    c->launch_cap = static_cast<uint32_t>(L);
     return PTGPU_OK;
 }
 
@@ -315,8 +319,12 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         const uint64_t n_batches = std::max<uint64_t>((total + c->chunk - 1) / c->chunk, 1);
         K = std::max<uint64_t>((((total + n_batches - 1) / n_batches) + 63ull) & ~63ull, 64);
     }
-    int rc = ensure_work_memory(c, fanout, bounces, K);
+    // Spawned generations outgrow the camera batch (up to ~3x for the branching PBR estimator); launching a whole
+    // generation at once saves the tail of every extra launch, so launches may be four batches long.
+    const uint64_t L_want = fanout ? std::min<uint64_t>(4 * K, 1ull << 28) : K;
+    int rc = ensure_work_memory(c, fanout, bounces, K, L_want);
     if (rc) return rc;
+    const uint64_t L = c->launch_cap;
     PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
     ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride};
     ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3);  // framebuffer.clear, renderer.cc:85
@@ -379,15 +387,17 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
                 if (op.top > f.floor_out) frames.push_back({f.pool ^ 1, f.floor_out, f.floor_in});
                 continue;
             }
-            uint64_t n64 = std::min<uint64_t>(K, in.top - f.floor_in);
+            uint64_t n64 = std::min<uint64_t>(L, in.top - f.floor_in);
             if (fanout) {
                 const uint64_t room = (op.cap - op.top) / fanout;
                 if (room < std::min<uint64_t>(n64, kMinLaunch)) {
-                    if (op.top <= f.floor_out)
+                    if (op.top > f.floor_out) {
+                        frames.push_back({f.pool ^ 1, f.floor_out, in.top});  // depth first: drain the spawned rays, then resume
+                        continue;
+                    }
+                    if (room == 0)  // nothing to drain and no room for one ray's offspring
                         return c->fail(PTGPU_E_NOMEM, "ray pool exhausted (%llu rays live); lower the chunk size",
                                        static_cast<unsigned long long>(in.top + op.top));
-                    frames.push_back({f.pool ^ 1, f.floor_out, in.top});  // depth first: drain the spawned rays, then resume
-                    continue;
                 }
                 n64 = std::min(n64, room);
             }
@@ -860,7 +870,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     const FrameGeometry g = frame_geometry(c, width, height);
     const uint64_t total = static_cast<uint64_t>(g.n_tiles) * 64ull;
     const uint64_t K = std::min<uint64_t>(std::min<uint64_t>(c->chunk, 1u << 22), total);
-    int rc = ensure_work_memory(c, 0, 0, K);
+    int rc = ensure_work_memory(c, 0, 0, K, K);
     if (rc) return rc;
     hipStream_t st = c->stream;
     const std::vector<float> sub = subsample_table(spp);
@@ -905,7 +915,7 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
     if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays: no scene loaded");
     PT_HIP(c, hipSetDevice(c->device));
     const uint64_t K = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(c->chunk, 1u << 22), n), 64);
-    int rc = ensure_work_memory(c, 0, 0, K);
+    int rc = ensure_work_memory(c, 0, 0, K, K);
     if (rc) return rc;
     hipStream_t st = c->stream;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
