@@ -1,6 +1,7 @@
 // Microbenchmark: rate of divergent 16-byte gathers through the per-CU vector L1 on gfx950.
 //   mode 0: one dwordx4 per lane from a random 64-byte record
 //   mode 1: four dwordx4 per lane covering one random 64-byte record (the traversal kernel's node fetch)
+//   mode 3: as mode 2 with the quad's record indices derived without a cross-lane shuffle (pure access-pattern rate)
 //   mode 2: quad-cooperative: the 4 lanes of a quad fetch the 4 quarters of one record per instruction, 4 instructions
 //           for the quad's 4 records (same bytes per lane as mode 1, coalesced inside the quad)
 #include <hip/hip_runtime.h>
@@ -27,6 +28,15 @@ __global__ __launch_bounds__(256) void gather(const float4* __restrict__ table, 
             const float4* p = table + static_cast<size_t>(rec) * 4;
             const float4 a = p[0], b = p[1], c = p[2], d = p[3];
             acc += a.x + b.y + c.z + d.w;
+        } else if (MODE == 3) {
+            const uint32_t q = threadIdx.x & 3u;
+            uint32_t qs = mix((gid >> 2) * 977u + it);  // the same in the 4 lanes of a quad
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                qs = mix(qs + k);
+                const float4 v = table[static_cast<size_t>(qs % n_records) * 4 + q];
+                acc += v.x + v.w;
+            }
         } else {
             const uint32_t q = threadIdx.x & 3u;
 #pragma unroll
@@ -55,7 +65,7 @@ int main(int argc, char** argv) {
         float4* table;
         hipMalloc(&table, static_cast<size_t>(n_records) * 64);
         hipMemset(table, 0, static_cast<size_t>(n_records) * 64);
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             for (int blocks_per_cu : {4, 8}) {
                 const int blocks = blocks_per_cu * cus, iters = 2000;
                 hipEvent_t e0, e1;
@@ -64,6 +74,7 @@ int main(int argc, char** argv) {
                     hipEventRecord(e0);
                     if (mode == 0) hipLaunchKernelGGL(gather<0>, dim3(blocks), dim3(256), 0, 0, table, n_records, iters, out);
                     if (mode == 1) hipLaunchKernelGGL(gather<1>, dim3(blocks), dim3(256), 0, 0, table, n_records, iters, out);
+                    if (mode == 3) hipLaunchKernelGGL(gather<3>, dim3(blocks), dim3(256), 0, 0, table, n_records, iters, out);
                     if (mode == 2) hipLaunchKernelGGL(gather<2>, dim3(blocks), dim3(256), 0, 0, table, n_records, iters, out);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
