@@ -100,6 +100,7 @@ struct SceneDev {
     const float4* env;
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)
     uint32_t n_instances;
+    uint32_t n_top_nodes;         // nodes[0 .. n_top_nodes) are the most visited ones (kept in LDS by the traversal kernel)
     int32_t env_w, env_h;
     float env_rot;
 };
