@@ -1159,22 +1159,33 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 #endif
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
+    // Three stages, so that no spawned ray has to wait in registers for the others:
+    //   A  everything up to the point where it is known WHICH of the four lobes spawn a ray (that needs the tangent
+    //      frame, the micro-normal and the refracted direction);
+    //   B  one queue reservation for the workgroup (ballots + one atomic);
+    //   C  each lobe's direction and weight, written straight to its reserved slot.
     stage_decode_tables(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
-    float4 no[4], nd[4], np[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) no[s] = nd[s] = np[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // state that survives from stage A to stage C
+    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro;
+    f3 payload = mk3(0.0f), position = mk3(0.0f), normal = mk3(0.0f), atten = mk3(1.0f), v = mk3(0.0f), m = mk3(0.0f), l_refr = mk3(0.0f);
+    f3 diffuse_color = mk3(0.0f), f0 = mk3(0.0f);
+    Tbn tbn{mk3(0.0f), mk3(0.0f), mk3(0.0f)};
+    float alpha = 0.0f, transmission = 0.0f, a_lin = 0.0f, eta = 1.0f, u0 = 0.0f, u1 = 0.0f;
+    uint32_t key = 0, nflags = 0;
+    bool exiting = false;
 
     if (i < n) {
-        const float4 ro = rays.o[i], rd = rays.d[i], rp = rays.p[i];
+        ro = rays.o[i];
+        rd = rays.d[i];
+        const float4 rp = rays.p[i];
         const float4 h0 = hits.h0[i];
         const uint32_t h1 = hits.h1[i];
         const uint32_t pid = __float_as_uint(ro.w);
-        const uint32_t key = __float_as_uint(rp.w);
-        const uint32_t flags = __float_as_uint(rd.w);
-        const uint32_t depth = flags & 0xffu;
-        const f3 payload = f3{rp.x, rp.y, rp.z};
+        key = __float_as_uint(rp.w);
+        const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
+        payload = f3{rp.x, rp.y, rp.z};
         const f3 dir = ld3(rd);
         f3 radiance = mk3(0.0f);
         if (!(h1 & 0x80000000u)) {
@@ -1185,24 +1196,17 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             sp.p.position = xform(sp.obj->model, sp.p.position, 1.0f);
             normals_to_world(sp);
             const DevMaterial& mat = sp.obj->mat;
-            bool exiting = false;
             if (backface) {
                 if (mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;
                 else if (mat.has_volume) exiting = true;
             }
+            position = sp.p.position;
+            normal = sp.p.normal;
             const float4 albedo = sample_albedo(sc, mat, sp.p.u, sp.p.v);
-            float alpha = albedo.w;
+            alpha = albedo.w;
             if (!mat.alpha_blending) alpha = (alpha < mat.alpha_cutoff) ? 0.0f : 1.0f;
-            if (alpha != 1.0f) {  // pass-through ray: same direction and depth (ray_program.cc:265-271)
-                const f3 org = sp.p.position + (exiting ? 1.0f : -1.0f) * sp.p.normal * 1e-5f;
-                const f3 pl = payload * (1.0f - alpha);
-                has[0] = true;
-                no[0] = make_float4(org.x, org.y, org.z, ro.w);
-                nd[0] = rd;
-                np[0] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_PASS)));
-            }
+            has[0] = (alpha != 1.0f);  // pass-through ray: same direction and depth (ray_program.cc:265-271)
             if (alpha != 0.0f) {
-                f3 atten = mk3(1.0f);
                 if (exiting) {  // volume absorption on the segment that leaves the volume (:278-279)
                     const f3 e = f3{-mat.attenuation[0], -mat.attenuation[1], -mat.attenuation[2]} * h0.x;
                     atten = f3{sel_min(pt_exp(e.x), 1.0f), sel_min(pt_exp(e.y), 1.0f), sel_min(pt_exp(e.z), 1.0f)};
@@ -1210,10 +1214,10 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                 const f3 emissive = sample_emissive(sc, mat, sp.p.u, sp.p.v);
                 radiance = payload * emissive * atten * alpha;
                 if (depth != 0) {
-                    const f3 v = -dir;
+                    v = -dir;
                     const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
                     // handle_TBN_creation (ray_program.cc:121-142)
-                    Tbn tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
+                    tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
                     const bool has_map = (nm.w != 0.0f);
                     f3 nv = has_map ? normal_map_to_world(nm, tbn) : tbn.n;
                     const bool impossible = dot3(exiting ? -v : v, nv) < 0.0f;
@@ -1224,85 +1228,98 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                     }
                     if (has_map || impossible) tbn = make_tbn(tbn.t, tbn.b, nv);
 
-                    const float transmission = sample_transmission(sc, mat, sp.p.u, sp.p.v);
+                    transmission = sample_transmission(sc, mat, sp.p.u, sp.p.v);
                     const float4 orm = sample_orm(sc, mat, sp.p.u, sp.p.v);
                     const f3 alb = f3{albedo.x, albedo.y, albedo.z};
-                    const f3 diffuse_color = (1.0f - orm.z) * alb;
-                    const f3 f0 = mix3(mk3(mat.f0), alb, orm.z);
-                    const f3 f90 = mk3(1.0f);
-                    const float a_lin = orm.y * orm.y;
-                    const uint32_t nflags = (depth - 1u) & 0xffu;
-                    const float u0 = rng_uniform(key, 0), u1 = rng_uniform(key, 1), u2 = rng_uniform(key, 2),
-                                u3 = rng_uniform(key, 3);
-
-                    if (any_ne(diffuse_color * (1.0f - transmission), mk3(0.0f))) {  // diffuse lobe (:306-323)
-                        const f3 l = normalize3(mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(u0, u1)));
-                        const f3 h = normalize3(v + l);
-                        const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
-                        const f3 F = mk3(1.0f) - fresnel_schlick(f0, f90, LdH);
-                        const f3 org = sp.p.position + sp.p.normal * 1e-5f;
-                        const f3 pl = F * diffuse_color * (1.0f - transmission) * atten * payload * alpha;
-                        has[1] = true;
-                        no[1] = make_float4(org.x, org.y, org.z, ro.w);
-                        nd[1] = make_float4(l.x, l.y, l.z, __uint_as_float(nflags));
-                        np[1] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_DIFFUSE)));
-                    }
-                    {   // micro-normal shared by transmission and reflection (:324-389)
-                        f3 m = mul_tbn(tbn.t, tbn.b, tbn.n, ggx_dir(u2, u3, a_lin));
-                        f3 N = tbn.n;
-                        f3 offset_dir = sp.p.normal;
-                        if (exiting) {
-                            m = m * -1.0f;
-                            N = N * -1.0f;
-                            offset_dir = offset_dir * -1.0f;
-                        }
-                        const float eta = (!exiting) ? 1.0f / mat.ior : mat.ior;
-                        f3 l = refract3(-v, m, eta);
-                        const float VdN = clampf(dot3(N, v), 1e-8f, 1.0f);
-                        const float VdM = clampf(dot3(v, m), 0.0f, 1.0f);
-                        const float LdM = clampf(dot3(l, -m), 0.0f, 1.0f);
-                        const f3 F = fresnel_schlick(f0, f90, (!exiting) ? VdM : LdM);
-                        if (any_ne(diffuse_color * transmission, mk3(0.0f)) && any_ne(l, mk3(0.0f))) {
-                            const f3 h = normalize3(-(eta * v + l));
-                            const float LdN = clampf(dot3(-N, l), 0.0f, 1.0f);
-                            const float G = v_smith_ggx(VdN, LdN, a_lin);
-                            const float NdM = clampf(dot3(N, m), 1e-8f, 1.0f);
-                            const float VdH = clampf(dot3((!exiting) ? v : -v, h), 0.0f, 1.0f);
-                            const float w = G * VdH * LdN / NdM;
-                            f3 brdf = (mk3(1.0f) - F) * w;
-                            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
-                            const f3 org = sp.p.position - offset_dir * 1e-5f;
-                            const f3 ln = normalize3(l);
-                            const f3 pl = diffuse_color * transmission * atten * brdf * payload * alpha;
-                            has[2] = true;
-                            no[2] = make_float4(org.x, org.y, org.z, ro.w);
-                            nd[2] = make_float4(ln.x, ln.y, ln.z, __uint_as_float(nflags));
-                            np[2] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_TRANSMIT)));
-                        }
-                        {   // specular reflection (:371-388)
-                            const f3 h = m;
-                            l = normalize3(reflect3(-v, h));
-                            const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
-                            const float LdN = clampf(dot3(N, l), 0.0f, 1.0f);
-                            const float NdH = clampf(dot3(N, h), 1e-8f, 1.0f);
-                            const float G = v_smith_ggx(VdN, LdN, a_lin);
-                            const float w = G * LdN * LdH / NdH;
-                            f3 brdf = F * w;
-                            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
-                            const f3 org = sp.p.position + offset_dir * 1e-5f;
-                            const f3 pl = atten * brdf * payload * alpha;
-                            has[3] = true;
-                            no[3] = make_float4(org.x, org.y, org.z, ro.w);
-                            nd[3] = make_float4(l.x, l.y, l.z, __uint_as_float(nflags));
-                            np[3] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, LOBE_REFLECT)));
-                        }
-                    }
+                    diffuse_color = (1.0f - orm.z) * alb;
+                    f0 = mix3(mk3(mat.f0), alb, orm.z);
+                    a_lin = orm.y * orm.y;
+                    nflags = (depth - 1u) & 0xffu;
+                    u0 = rng_uniform(key, 0);
+                    u1 = rng_uniform(key, 1);
+                    const float u2 = rng_uniform(key, 2), u3 = rng_uniform(key, 3);
+                    // micro-normal shared by transmission and reflection (:324-389)
+                    m = mul_tbn(tbn.t, tbn.b, tbn.n, ggx_dir(u2, u3, a_lin));
+                    if (exiting) m = m * -1.0f;
+                    eta = (!exiting) ? 1.0f / mat.ior : mat.ior;
+                    l_refr = refract3(-v, m, eta);
+                    has[1] = any_ne(diffuse_color * (1.0f - transmission), mk3(0.0f));
+                    has[2] = any_ne(diffuse_color * transmission, mk3(0.0f)) && any_ne(l_refr, mk3(0.0f));
+                    has[3] = true;
                 }
             }
         }
         add_radiance(fb, pid, radiance);
     }
-    append_rays<4>(has, no, nd, np, out, out_count);
+
+    // ---- stage B: slots for the rays of this workgroup; lobe-major inside a wavefront ----
+    const uint32_t lane_id = threadIdx.x & 63u;
+    const unsigned long long lt = (1ull << lane_id) - 1ull;
+    uint32_t offs[4];
+    uint32_t total = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const unsigned long long mask = __ballot(has[s]);
+        offs[s] = total + __popcll(mask & lt);
+        total += __popcll(mask);
+    }
+    const uint32_t base = block_reserve(total, out_count);
+    auto emit = [&](int s, f3 org, float4 d4, f3 pl, uint32_t lobe) {
+        const uint32_t dst = base + offs[s];
+        out.o[dst] = make_float4(org.x, org.y, org.z, ro.w);
+        out.d[dst] = d4;
+        out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
+    };
+
+    // ---- stage C ----
+    if (has[0]) emit(0, position + (exiting ? 1.0f : -1.0f) * normal * 1e-5f, rd, payload * (1.0f - alpha), LOBE_PASS);
+    if (has[3]) {  // every lane that reaches the lobes has the reflection lobe
+        const f3 f90 = mk3(1.0f);
+        if (has[1]) {  // diffuse lobe (:306-323)
+            const f3 l = normalize3(mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(u0, u1)));
+            const f3 h = normalize3(v + l);
+            const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
+            const f3 F = mk3(1.0f) - fresnel_schlick(f0, f90, LdH);
+            const f3 pl = F * diffuse_color * (1.0f - transmission) * atten * payload * alpha;
+            emit(1, position + normal * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_DIFFUSE);
+        }
+        f3 N = tbn.n;
+        f3 offset_dir = normal;
+        if (exiting) {
+            N = N * -1.0f;
+            offset_dir = offset_dir * -1.0f;
+        }
+        const float VdN = clampf(dot3(N, v), 1e-8f, 1.0f);
+        const float VdM = clampf(dot3(v, m), 0.0f, 1.0f);
+        const float LdM = clampf(dot3(l_refr, -m), 0.0f, 1.0f);
+        const f3 F = fresnel_schlick(f0, f90, (!exiting) ? VdM : LdM);
+        if (has[2]) {  // transmission (:345-370)
+            const f3 h = normalize3(-(eta * v + l_refr));
+            const float LdN = clampf(dot3(-N, l_refr), 0.0f, 1.0f);
+            const float G = v_smith_ggx(VdN, LdN, a_lin);
+            const float NdM = clampf(dot3(N, m), 1e-8f, 1.0f);
+            const float VdH = clampf(dot3((!exiting) ? v : -v, h), 0.0f, 1.0f);
+            const float w = G * VdH * LdN / NdM;
+            f3 brdf = (mk3(1.0f) - F) * w;
+            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
+            const f3 ln = normalize3(l_refr);
+            const f3 pl = diffuse_color * transmission * atten * brdf * payload * alpha;
+            emit(2, position - offset_dir * 1e-5f, make_float4(ln.x, ln.y, ln.z, __uint_as_float(nflags)), pl, LOBE_TRANSMIT);
+        }
+        {   // specular reflection (:371-388)
+            const f3 h = m;
+            const f3 l = normalize3(reflect3(-v, h));
+            const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
+            const float LdN = clampf(dot3(N, l), 0.0f, 1.0f);
+            const float NdH = clampf(dot3(N, h), 1e-8f, 1.0f);
+            const float G = v_smith_ggx(VdN, LdN, a_lin);
+            const float w = G * LdN * LdH / NdH;
+            f3 brdf = F * w;
+            brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
+            const f3 pl = atten * brdf * payload * alpha;
+            emit(3, position + offset_dir * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_REFLECT);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
