@@ -35,6 +35,10 @@ CONFIGS = {
     "ao_1080p": dict(program=1, width=1920, height=1080, spp=64, bounces=1, newrays=8, scene="readme", env="white"),
     "raycast_640": dict(program=0, width=640, height=360, spp=1, bounces=4, newrays=0, scene="readme", env="white"),
     "stress_4k": dict(program=2, width=3840, height=2160, spp=256, bounces=8, newrays=0, scene="stress", env="white"),
+    # 12 bounces with every lobe followed is ~1000 rays per sample on this scene; the single-path estimator (one ray per
+    # hit, same expectation) is what makes the configuration renderable
+    "material_4k": dict(program=2, width=3840, height=2160, spp=4096, bounces=12, newrays=0, scene="material", env="farmland",
+                        single=True),
 }
 
 
@@ -42,6 +46,8 @@ def build_scene(kind: str, detail: float, stress_tris: int):
     from pathtracer_amd import scenes
     if kind == "stress":
         return scenes.stress_mesh(stress_tris)
+    if kind == "material":
+        return scenes.material_stress(detail=detail)
     return scenes.readme_standin(detail=detail)
 
 
@@ -62,7 +68,8 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
     cam = model.cameras[0]
 
     def scene_for(spp):
-        st = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1)
+        st = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
+                          abi.FLAG_SINGLE_PATH if cfg.get("single") else 0)
         s = ob.OracleScene(model, env, st)
         s.update_camera_transform_state(cam.position, cam.direction, cam.up, cam.yfov, w / h, cam.znear, cam.zfar)
         s.set_math_mode(ob.MATH_LIBM)
@@ -75,7 +82,8 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
     per_spp = st.seconds / probe_spp
     spp = int(max(probe_spp, min(cfg["spp"], seconds_target / max(per_spp, 1e-9))))
     if spp > probe_spp:
-        st_abi = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1)
+        st_abi = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
+                              abi.FLAG_SINGLE_PATH if cfg.get("single") else 0)
         s.set_settings(st_abi)
         _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
         rate = st.rays / max(st.seconds, 1e-9)
@@ -99,6 +107,7 @@ def main() -> None:
     ap.add_argument("--bounces", type=int, default=-1)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--single-path", action="store_true", help="PBR: one spawned ray per hit (same expectation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -112,6 +121,8 @@ def main() -> None:
         cfg["width"] = args.width
     if args.height:
         cfg["height"] = args.height
+    if args.single_path:
+        cfg["single"] = True
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,7 +151,8 @@ def main() -> None:
     w, h = cfg["width"], cfg["height"]
     from pathtracer_amd.distributed import combine_partial_sums, subset_settings
     settings = subset_settings(RenderSettings(cfg["spp"], cfg["bounces"], cfg["newrays"], 8, 0.0,
-                                              RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234),
+                                              RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
+                                              singlePath=bool(cfg.get("single"))),
                                rank, world)
     r = Renderer(device_index)
     r.set_render_settings(settings)
@@ -215,7 +227,8 @@ def main() -> None:
                     + ("assets/farmland_overcast_1k.hdr environment" if cfg["env"] == "farmland" else "white environment"),
             "config": {
                 "workload": f"{args.config}: program={RayProgramMode(cfg['program']).name} BVH {w}x{h} {cfg['spp']}spp "
-                            f"{cfg['bounces']} bounces, {model.instanced_triangles()} instanced triangles, "
+                            f"{cfg['bounces']} bounces{' single-path' if cfg.get('single') else ''}, "
+                            f"{model.instanced_triangles()} instanced triangles, "
                             f"{len(model.objects)} objects",
                 "parallelism": f"sample-split x{world}" + ((" + RCCL" if backend == "nccl" else f" + {backend}") + " reduce(sum) to rank 0" if world > 1 else ""),
                 "scene_load_s": round(t_load, 2),
@@ -228,7 +241,8 @@ def main() -> None:
             # triangle, and writes a 20 B hit record.  The instance pass before it (tlas_kernel) reads 32 B + 64 B per
             # tested instance bound and writes the candidate list; it is timed inside extend_ms but not in traverse_ms.
             count_settings = RenderSettings(min(cfg["spp"], 8), cfg["bounces"], cfg["newrays"], 8, 0.0,
-                                            RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234)
+                                            RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
+                                            singlePath=bool(cfg.get("single")))
             r.set_render_settings(count_settings)
             _, cst = r.render_counted(w, h)
             r.set_render_settings(settings)

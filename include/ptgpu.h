@@ -137,7 +137,15 @@ typedef struct ptgpu_settings {
     uint32_t seed;
     uint32_t sample_begin; /* first global sample index rendered here (default 0) */
     uint32_t sample_step;  /* stride between rendered sample indices (default 1; 0 means 1) */
+    uint32_t flags;        /* PTGPU_FLAG_*, default 0 */
 } ptgpu_settings;
+
+/* PBR only, no counterpart in the reference (whose estimator follows every lobe
+ * of every hit, src/ray_program.cc:265-388): of the rays a hit would spawn, one
+ * is kept, chosen with probability proportional to the largest component of its
+ * payload, and its payload is divided by that probability.  Same expectation,
+ * at most one ray per hit, so deep bounce limits stay affordable. */
+#define PTGPU_FLAG_SINGLE_PATH 1u
 
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */

@@ -514,10 +514,45 @@ struct Programs {
         }
         return ray.payload * emissive * atten * alpha;
     }
+    // Single-path PBR (no counterpart in the reference, whose estimator follows every lobe): of the rays one hit
+    // would spawn, one is kept, chosen with probability proportional to the largest component of its payload, and
+    // its payload is divided by that probability — the same expectation with at most one ray per hit, which is
+    // what makes deep bounce limits affordable.  The BRDF clamp is already inside the payloads when they are
+    // weighed.  Order of the candidates: pass-through, diffuse, transmission, reflection.
+    static float lobe_weight(V3 p) {
+        float w = std::fabs(p.x);
+        if (std::fabs(p.y) > w) w = std::fabs(p.y);
+        if (std::fabs(p.z) > w) w = std::fabs(p.z);
+        return ((w > 0.0f) && (w < kInf)) ? w : 0.0f;  // NaN, infinite and zero payloads are never chosen
+    }
+    V3 pbr_single(const RayP& ray, const TriHit& hit, std::vector<RayP>& out, Sampler& smp) const {
+        static thread_local std::vector<RayP> cand;
+        cand.clear();
+        V3 radiance = pbr(ray, hit, cand, smp);
+        if (cand.empty()) return radiance;
+        float w[4] = {0.0f, 0.0f, 0.0f, 0.0f}, c[4];
+        float total = 0.0f;
+        for (size_t k = 0; k < cand.size(); ++k) {
+            w[k] = lobe_weight(cand[k].payload);
+            total = total + w[k];
+            c[k] = total;
+        }
+        if (!(total > 0.0f)) return radiance;  // nothing the children could add
+        const float x = smp.draw(ray, 4) * total;
+        size_t pick = cand.size() - 1;
+        for (size_t k = cand.size(); k-- > 0;)
+            if (x < c[k]) pick = k;
+        while (w[pick] == 0.0f) --pick;  // only when x landed on the total by rounding: the last candidate with weight
+        RayP nr = cand[pick];
+        nr.payload = nr.payload * (total / w[pick]);
+        out.push_back(nr);
+        return radiance;
+    }
+    bool single_path = false;
     V3 on_hit(int mode, const RayP& ray, const TriHit& hit, std::vector<RayP>& out, Sampler& smp) const {
         switch (mode) {
             case 1: return ao(ray, hit, out, smp);
-            case 2: return pbr(ray, hit, out, smp);
+            case 2: return single_path ? pbr_single(ray, hit, out, smp) : pbr(ray, hit, out, smp);
             default: return raycast(ray, hit);
         }
     }
@@ -710,6 +745,7 @@ orc_scene* orc_scene_create(const orc_model* model, const orc_envmap* env, const
     s->programs.env_rot = settings->envmap_rotation;
     s->programs.ao_samples = settings->max_new_rays_per_bounce;
     s->programs.inv_ao = 1.0f / static_cast<float>(settings->max_new_rays_per_bounce);  // ray_program.cc:167
+    s->programs.single_path = (settings->flags & ORC_FLAG_SINGLE_PATH) != 0;
     return s;
 }
 void orc_scene_destroy(orc_scene* s) { delete s; }
@@ -719,6 +755,8 @@ void orc_set_settings(orc_scene* s, const orc_settings* st) {
     s->settings.seed = st->seed;
     s->settings.sample_begin = st->sample_begin;
     s->settings.sample_step = st->sample_step;
+    s->settings.flags = st->flags;
+    s->programs.single_path = (st->flags & ORC_FLAG_SINGLE_PATH) != 0;
 }
 void orc_set_rng_mode(orc_scene* s, int m) { s->rng_mode = m; }
 void orc_set_math_mode(orc_scene* s, int m) { s->programs.mx.mode = m; }

@@ -103,7 +103,9 @@ typedef struct orc_settings {
     uint32_t seed;
     uint32_t sample_begin;
     uint32_t sample_step;
+    uint32_t flags; /* ORC_FLAG_* */
 } orc_settings;
+#define ORC_FLAG_SINGLE_PATH 1u /* PBR keeps one of the rays a hit would spawn (see Programs::pbr_single) */
 
 typedef struct orc_hit {
     float t, A, B;

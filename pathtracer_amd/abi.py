@@ -86,7 +86,11 @@ class Settings(C.Structure):
         ("seed", C.c_uint32),
         ("sample_begin", C.c_uint32),
         ("sample_step", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
+
+
+FLAG_SINGLE_PATH = 1
 
 
 class Hit(C.Structure):

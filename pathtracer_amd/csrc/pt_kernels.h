@@ -74,8 +74,9 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
                               uint32_t* spill, uint32_t spill_depth, uint32_t n_blocks, uint32_t* next_ray, uint32_t* overflow,
                               TraceCounters* counters, hipEvent_t between = nullptr);
 // program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
+// single_path (PBR): at most one spawned ray per hit, chosen in proportion to its payload and reweighted.
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
-                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples);
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path = false);
 void launch_clear(hipStream_t st, float* p, uint64_t n);
 // planar tiled sums -> row-major RGBA: rgb = sum / divisor (samples for the mean, 1 for raw sums), a = alpha
 void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha);

@@ -11,6 +11,7 @@
 // One lane owns one ray.  Traversal stacks are per lane: the first kStackLds entries of every lane
 // live in LDS as stack[entry][lane] (bank = lane % 32 for every entry, so pushes and pops never
 // conflict whatever the lanes' stack heights); deeper entries go to a per-lane HBM spill area.
+#include <type_traits>
 #include "pt_kernels.h"
 
 #include <algorithm>
@@ -1157,6 +1158,15 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 #else
 #define PT_SHADE_BOUNDS __launch_bounds__(kBlock)
 #endif
+// Largest component of a payload as a selection weight; NaN, infinite and zero payloads are never chosen.
+__device__ __forceinline__ float lobe_weight(f3 p) {
+    float w = fabsf(p.x);
+    if (fabsf(p.y) > w) w = fabsf(p.y);
+    if (fabsf(p.z) > w) w = fabsf(p.z);
+    return ((w > 0.0f) && (w < kInfF)) ? w : 0.0f;
+}
+
+template <bool SINGLE>
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
     // Three stages, so that no spawned ray has to wait in registers for the others:
@@ -1164,6 +1174,9 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     //      frame, the micro-normal and the refracted direction);
     //   B  one queue reservation for the workgroup (ballots + one atomic);
     //   C  each lobe's direction and weight, written straight to its reserved slot.
+    // SINGLE (no counterpart in the reference): the lobes are computed first, one of them is kept — chosen with
+    // probability proportional to the largest component of its payload, payload divided by that probability — and
+    // the reservation is for that one ray.
     stage_decode_tables(sc);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
@@ -1252,27 +1265,16 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         add_radiance(fb, pid, radiance);
     }
 
-    // ---- stage B: slots for the rays of this workgroup; lobe-major inside a wavefront ----
     const uint32_t lane_id = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane_id) - 1ull;
-    uint32_t offs[4];
-    uint32_t total = 0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const unsigned long long mask = __ballot(has[s]);
-        offs[s] = total + __popcll(mask & lt);
-        total += __popcll(mask);
-    }
-    const uint32_t base = block_reserve(total, out_count);
-    auto emit = [&](int s, f3 org, float4 d4, f3 pl, uint32_t lobe) {
-        const uint32_t dst = base + offs[s];
+    auto store = [&](uint32_t dst, f3 org, float4 d4, f3 pl, uint32_t lobe) {
         out.o[dst] = make_float4(org.x, org.y, org.z, ro.w);
         out.d[dst] = d4;
         out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
     };
-
-    // ---- stage C ----
-    if (has[0]) emit(0, position + (exiting ? 1.0f : -1.0f) * normal * 1e-5f, rd, payload * (1.0f - alpha), LOBE_PASS);
+    // ---- stage C: the lobes; `emit(s, ...)` is called with s = the lobe's number (LOBE_PASS .. LOBE_REFLECT) ----
+    auto lobes = [&](auto&& emit) {
+    if (has[0]) emit(std::integral_constant<int, 0>{}, position + (exiting ? 1.0f : -1.0f) * normal * 1e-5f, rd, payload * (1.0f - alpha), LOBE_PASS);
     if (has[3]) {  // every lane that reaches the lobes has the reflection lobe
         const f3 f90 = mk3(1.0f);
         if (has[1]) {  // diffuse lobe (:306-323)
@@ -1281,7 +1283,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
             const f3 F = mk3(1.0f) - fresnel_schlick(f0, f90, LdH);
             const f3 pl = F * diffuse_color * (1.0f - transmission) * atten * payload * alpha;
-            emit(1, position + normal * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_DIFFUSE);
+            emit(std::integral_constant<int, 1>{}, position + normal * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_DIFFUSE);
         }
         f3 N = tbn.n;
         f3 offset_dir = normal;
@@ -1304,7 +1306,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
             const f3 ln = normalize3(l_refr);
             const f3 pl = diffuse_color * transmission * atten * brdf * payload * alpha;
-            emit(2, position - offset_dir * 1e-5f, make_float4(ln.x, ln.y, ln.z, __uint_as_float(nflags)), pl, LOBE_TRANSMIT);
+            emit(std::integral_constant<int, 2>{}, position - offset_dir * 1e-5f, make_float4(ln.x, ln.y, ln.z, __uint_as_float(nflags)), pl, LOBE_TRANSMIT);
         }
         {   // specular reflection (:371-388)
             const f3 h = m;
@@ -1317,8 +1319,54 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             f3 brdf = F * w;
             brdf = f3{sel_min(brdf.x, 10.0f), sel_min(brdf.y, 10.0f), sel_min(brdf.z, 10.0f)};
             const f3 pl = atten * brdf * payload * alpha;
-            emit(3, position + offset_dir * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_REFLECT);
+            emit(std::integral_constant<int, 3>{}, position + offset_dir * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_REFLECT);
         }
+    }
+    };
+
+    if constexpr (!SINGLE) {
+        // ---- stage B: slots for the rays of this workgroup; lobe-major inside a wavefront ----
+        uint32_t offs[4];
+        uint32_t total = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned long long mask = __ballot(has[s]);
+            offs[s] = total + __popcll(mask & lt);
+            total += __popcll(mask);
+        }
+        const uint32_t base = block_reserve(total, out_count);
+        lobes([&](auto s, f3 org, float4 d4, f3 pl, uint32_t lobe) { store(base + offs[decltype(s)::value], org, d4, pl, lobe); });
+    } else {
+        f3 org0 = mk3(0.0f), org1 = org0, org2 = org0, org3 = org0, pl0 = org0, pl1 = org0, pl2 = org0, pl3 = org0;
+        float4 d0 = ro, d1 = ro, d2 = ro, d3 = ro;
+        lobes([&](auto s, f3 org, float4 d4, f3 pl, uint32_t) {
+            constexpr int k = decltype(s)::value;
+            if constexpr (k == 0) { org0 = org; d0 = d4; pl0 = pl; }
+            if constexpr (k == 1) { org1 = org; d1 = d4; pl1 = pl; }
+            if constexpr (k == 2) { org2 = org; d2 = d4; pl2 = pl; }
+            if constexpr (k == 3) { org3 = org; d3 = d4; pl3 = pl; }
+        });
+        // cumulative weights in lobe order; an absent lobe has weight 0 and is never the first to exceed x
+        const float w0 = has[0] ? lobe_weight(pl0) : 0.0f, w1 = has[1] ? lobe_weight(pl1) : 0.0f;
+        const float w2 = has[2] ? lobe_weight(pl2) : 0.0f, w3 = has[3] ? lobe_weight(pl3) : 0.0f;
+        const float c0 = w0, c1 = c0 + w1, c2 = c1 + w2, total_w = c2 + w3;
+        const bool any = total_w > 0.0f;
+        int pick = 3;
+        if (any) {
+            const float x = rng_uniform(key, 4) * total_w;
+            if (x < c2) pick = 2;
+            if (x < c1) pick = 1;
+            if (x < c0) pick = 0;
+            // only when x landed on the total by rounding: the last lobe with a weight
+            if (pick == 3 && w3 == 0.0f) pick = (w2 != 0.0f) ? 2 : ((w1 != 0.0f) ? 1 : 0);
+        }
+        const float wp = (pick == 0) ? w0 : (pick == 1) ? w1 : (pick == 2) ? w2 : w3;
+        const f3 org = (pick == 0) ? org0 : (pick == 1) ? org1 : (pick == 2) ? org2 : org3;
+        const float4 d4 = (pick == 0) ? d0 : (pick == 1) ? d1 : (pick == 2) ? d2 : d3;
+        const f3 pl = (pick == 0) ? pl0 : (pick == 1) ? pl1 : (pick == 2) ? pl2 : pl3;
+        const unsigned long long mask = __ballot(any);
+        const uint32_t base = block_reserve(__popcll(mask), out_count);
+        if (any) store(base + __popcll(mask & lt), org, d4, pl * (total_w / wp), static_cast<uint32_t>(pick));
     }
 }
 
@@ -1410,13 +1458,15 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
     }
 }
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
-                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples) {
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path) {
     if (!n) return;
     const dim3 grid(blocks_for(n)), block(kBlock);
     if (program == 1)
         hipLaunchKernelGGL(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
+    else if (program == 2 && single_path)
+        hipLaunchKernelGGL(shade_pbr_kernel<true>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
     else if (program == 2)
-        hipLaunchKernelGGL(shade_pbr_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
+        hipLaunchKernelGGL(shade_pbr_kernel<false>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
     else
         hipLaunchKernelGGL(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
 }

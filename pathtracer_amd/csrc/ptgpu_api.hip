@@ -224,7 +224,8 @@ FrameGeometry frame_geometry(const ptgpu_ctx* c, int w, int h) {
 }
 
 uint32_t fanout_of(const ptgpu_settings& s) {
-    if (s.program_mode == PTGPU_PROGRAM_PBR) return 4;  // pass-through + diffuse + transmission + reflection
+    if (s.program_mode == PTGPU_PROGRAM_PBR)  // pass-through + diffuse + transmission + reflection, or the one of them kept
+        return (s.flags & PTGPU_FLAG_SINGLE_PATH) ? 1 : 4;
     if (s.program_mode == PTGPU_PROGRAM_AO) return s.max_new_rays_per_bounce;
     return 0;
 }
@@ -322,7 +323,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     }
     // Spawned generations outgrow the camera batch (up to ~3x for the branching PBR estimator); launching a whole
     // generation at once saves the tail of every extra launch, so launches may be four batches long.
-    const uint64_t L_want = fanout ? std::min<uint64_t>(4 * K, 1ull << 28) : K;
+    const uint64_t L_want = fanout > 1 ? std::min<uint64_t>(4 * K, 1ull << 28) : K;
     int rc = ensure_work_memory(c, fanout, bounces, K, L_want);
     if (rc) return rc;
     const uint64_t L = c->launch_cap;
@@ -419,7 +420,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             PT_HIP(c, hipEventRecord(c->ev[1], st));
             if (fanout) PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
             PT_HIP(c, hipEventRecord(c->ev[2], st));
-            ptd::launch_shade(st, program, sc, rq, n, hits, op.at(op.top), d_count, fb, ao_samples);
+            ptd::launch_shade(st, program, sc, rq, n, hits, op.at(op.top), d_count, fb, ao_samples,
+                              (s.flags & PTGPU_FLAG_SINGLE_PATH) != 0);
             PT_HIP(c, hipEventRecord(c->ev[3], st));
             if (fanout) PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
             PT_HIP(c, hipStreamSynchronize(st));
@@ -560,6 +562,7 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
     if (!c || !s) return PTGPU_E_INVALID;
     if (s->program_mode < 0 || s->program_mode > 2 || s->accel_struct_type < 0 || s->accel_struct_type > 1)
         return c->fail(PTGPU_E_INVALID, "set_render_settings: program_mode / accel_struct_type out of range");
+    if (s->flags & ~PTGPU_FLAG_SINGLE_PATH) return c->fail(PTGPU_E_INVALID, "set_render_settings: unknown flag bits 0x%x", s->flags);
     c->settings = *s;
     return PTGPU_OK;
 }

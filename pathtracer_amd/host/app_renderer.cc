@@ -416,6 +416,7 @@ void Renderer::push_settings() {
     s.seed = seed_;
     s.sample_begin = 0;
     s.sample_step = 1;
+    s.flags = single_path_ ? PTGPU_FLAG_SINGLE_PATH : 0u;
     const int rc = ptgpu_set_render_settings(ctx_, &s);
     if (rc != PTGPU_OK) fail("ptgpu_set_render_settings", rc);
 }

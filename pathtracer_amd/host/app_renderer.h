@@ -32,6 +32,7 @@ class Renderer {
 
     // additions of the GPU build
     void set_seed(uint32_t seed) { seed_ = seed; push_settings(); }
+    void set_single_path(bool on) { single_path_ = on; push_settings(); }  // PTGPU_FLAG_SINGLE_PATH
     const ptgpu_stats& last_stats() const { return stats_; }
     // closest hit of sample `sample` of every pixel, row-major (the raycast parity dump)
     std::vector<ptgpu_hit> render_hits(int width, int height, uint32_t sample = 0);
@@ -43,6 +44,7 @@ class Renderer {
     ptgpu_ctx* ctx_ = nullptr;
     RenderSettings renderSettings_;
     uint32_t seed_ = 0;
+    bool single_path_ = false;
     ptgpu_stats stats_{};
 };
 

@@ -153,6 +153,49 @@ def test_images_match_oracle(tiny, program, spp, bounces, newrays, wh):
     assert not bad.any(), f"{bad.sum()} channel values beyond tolerance, max diff {np.abs(img_g - img_o).max()}"
 
 
+@pytest.fixture(scope="module")
+def materials():
+    return scenes.material_stress(detail=0.1), scenes.synthetic_env()
+
+
+@pytest.mark.parametrize("spp,bounces,single,wh", [
+    (3, 12, False, (64, 36)),    # every lobe followed to 12 bounces: ~1000 rays per sample on this scene
+    (32, 12, True, (64, 36)),    # one ray per hit
+    (5, 255, True, (33, 19)),    # the deepest bounce limit the settings can express
+])
+def test_material_scene_matches_oracle(materials, spp, bounces, single, wh):
+    """BASELINE configuration 5's scene kind (transmissive + volume + ior, alpha mask, alpha blend, emissive, normal
+    map) at its bounce limit, small frame: equal ray counts, pixels within 2e-5 * max(1, value)."""
+    model, env = materials
+    w, h = wh
+    st = H.settings(program=2, spp=spp, bounces=bounces, single=single)
+    g, o = H.make_gpu(model, env, st, w, h), H.make_oracle(model, env, st, w, h)
+    img_o, so = o.render_frame(w, h)
+    img_g, sg = H.gpu_render(g, w, h)
+    assert sg.rays == so.rays and sg.camera_samples == so.camera_samples == w * h * spp
+    assert np.isfinite(img_g).all()
+    tol = 2e-5 * np.maximum(1.0, np.abs(img_o[..., :3]))
+    bad = np.abs(img_g[..., :3] - img_o[..., :3]) > tol
+    assert not bad.any(), f"{bad.sum()} channel values beyond tolerance, max diff {np.abs(img_g - img_o).max()}"
+
+
+def test_single_path_on_tiny_scene_matches_oracle_and_literal_mean(tiny):
+    """Single-path mode: ray for ray the oracle's; and the same expectation as the estimator that follows every
+    lobe (whole-image mean within 1 %, both at 1024 spp: same sub-pixel table)."""
+    model, env = tiny
+    w, h = 64, 36
+    st = H.settings(program=2, spp=1024, bounces=6, single=True)
+    g, o = H.make_gpu(model, env, st, w, h), H.make_oracle(model, env, st, w, h)
+    img_g, sg = H.gpu_render(g, w, h)
+    img_o, so = o.render_frame(w, h)
+    assert sg.rays == so.rays
+    assert (np.abs(img_g[..., :3] - img_o[..., :3]) <= 2e-5 * np.maximum(1.0, np.abs(img_o[..., :3]))).all()
+    g.set_render_settings(H.settings(program=2, spp=1024, bounces=6, seed=77))
+    lit, sl = H.gpu_render(g, w, h)
+    assert sl.rays / sl.camera_samples > 3 * sg.rays / sg.camera_samples
+    assert abs(lit[..., :3].mean() - img_g[..., :3].mean()) <= 0.01 * lit[..., :3].mean()
+
+
 def test_golden_converged_images(tiny, golden):
     model, env = tiny
     w, h = 64, 36
@@ -336,3 +379,30 @@ def test_full_size_stress_geometry_properties():
     d = np.abs(img[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
     assert (d <= 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).all(), d.max()
     assert (hits["hit"] != 0).mean() > 0.2
+
+
+def test_full_size_material_stress_properties():
+    """BASELINE configuration 5's shape — 3840x2160, 4096 spp (the 64x64 sub-pixel grid), 12 bounces, transmissive /
+    alpha / emissive materials — rendered the way one of 256 ranks would: every 256th sample of each pixel, single-path
+    mode (following every lobe costs ~1000 rays per sample at this depth).  A band of rows equals the oracle, ray counts
+    agree on it, two disjoint sample subsets add up to their union, the frame is finite."""
+    import torch
+    model, env = scenes.material_stress(detail=1.0), scenes.synthetic_env()
+    w, h, spp = 3840, 2160, 4096
+    st = H.settings(program=2, spp=spp, bounces=12, single=True, begin=5, step=256)
+    g = H.make_gpu(model, env, st, w, h)
+    img, s = H.gpu_render(g, w, h)
+    assert np.isfinite(img).all() and s.camera_samples == w * h * 16 and s.rays > s.camera_samples
+    rows = (1079, 1081)
+    o = H.make_oracle(model, env, st, w, h)
+    band, so = o.render_frame(w, h, rows=rows)
+    d = np.abs(img[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
+    assert (d <= 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).all(), d.max()
+    parts = []
+    for begin in (5, 261):
+        buf = torch.zeros((h, w, 4), device="cuda")
+        g.set_render_settings(H.settings(program=2, spp=spp, bounces=12, single=True, begin=begin, step=512))
+        g.render_frame_sums(w, h, buf.data_ptr())
+        parts.append(buf)
+    both = ((parts[0] + parts[1])[..., :3] / 16).cpu().numpy()
+    assert np.allclose(both, img[..., :3], rtol=1e-5, atol=1e-6)
