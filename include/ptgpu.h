@@ -39,7 +39,11 @@ extern "C" {
 
 /* ---- enums (reference src/arguments.h:10-23) --------------------------- */
 enum { PTGPU_PROGRAM_RAYCASTER = 0, PTGPU_PROGRAM_AO = 1, PTGPU_PROGRAM_PBR = 2 };
-enum { PTGPU_AS_NAIVE = 0, PTGPU_AS_BVH = 1 };
+/* PTGPU_AS_LBVH has no counterpart in the reference: the same two-level structure with the per-mesh trees built
+ * on the GPU (Morton-ordered linear BVH) instead of by the host's binned-SAH builder — a much faster scene load for
+ * multi-million-triangle meshes, a somewhat slower traversal.  Closest hits are those of PTGPU_AS_BVH except
+ * where two triangles tie in distance. */
+enum { PTGPU_AS_NAIVE = 0, PTGPU_AS_BVH = 1, PTGPU_AS_LBVH = 2 };
 
 /* ---- scene data contract (reference src/model_loader.h:14-65) ---------- */
 

@@ -204,6 +204,8 @@ void build_range(std::vector<ptd::DevTri>& tris, Task first, uint32_t max_leaf, 
     }
 }
 
+}  // namespace
+
 void collect_info(MeshTree& t, uint32_t n_real_tris) {  // collect_tree_info, :538-570
     ptgpu_bvh_info r{};
     r.min_depth = 0xffffffffu;
@@ -241,8 +243,6 @@ void collect_info(MeshTree& t, uint32_t n_real_tris) {  // collect_tree_info, :5
     r.checksum = h;
     t.info = r;
 }
-
-}  // namespace
 
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
                      bool single_leaf, MeshTree& out) {

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "ptgpu.h"
@@ -27,6 +28,16 @@ struct MeshTree {
 // into one leaf in mesh order (the brute-force NaiveAS of acceleration_structure.cc:299-340).
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
                      bool single_leaf, MeshTree& out);
+
+// Device-side alternative (pt_lbvh.hip): a linear BVH over Morton-ordered triangles, built on the GPU of the current
+// device and read back into the same structure.  Different tree, same closest hits (up to ties in distance).
+// Returns false with a message in *err when a HIP call fails.
+bool build_mesh_tree_lbvh(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf, hipStream_t st,
+                          MeshTree& out, std::string* err);
+
+// Statistics of a finished tree (collect_tree_info, acceleration_structure.cc:538-570) into t.info;
+// n_real_tris = 0 for the placeholder leaf of an empty mesh.
+void collect_info(MeshTree& t, uint32_t n_real_tris);
 
 // Add base offsets to every reference so the tree can live at nodes[node_base...] / tris[tri_base...].
 void relocate(MeshTree& t, uint32_t node_base, uint32_t tri_base);

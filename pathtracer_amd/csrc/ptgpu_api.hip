@@ -560,7 +560,7 @@ const char* ptgpu_last_error(const ptgpu_ctx* c) { return c ? c->error.c_str() :
 
 int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
     if (!c || !s) return PTGPU_E_INVALID;
-    if (s->program_mode < 0 || s->program_mode > 2 || s->accel_struct_type < 0 || s->accel_struct_type > 1)
+    if (s->program_mode < 0 || s->program_mode > 2 || s->accel_struct_type < 0 || s->accel_struct_type > 2)
         return c->fail(PTGPU_E_INVALID, "set_render_settings: program_mode / accel_struct_type out of range");
     if (s->flags & ~PTGPU_FLAG_SINGLE_PATH) return c->fail(PTGPU_E_INVALID, "set_render_settings: unknown flag bits 0x%x", s->flags);
     c->settings = *s;
@@ -620,7 +620,14 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     for (uint32_t i = 0; i < model->n_meshes; ++i) {
         const ptgpu_mesh& m = model->meshes[i];
         pth::MeshTree tree;
-        pth::build_mesh_tree(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf, naive, tree);
+        if (s.accel_struct_type == PTGPU_AS_LBVH) {
+            std::string err;
+            if (!pth::build_mesh_tree_lbvh(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf,
+                                           c->stream, tree, &err))
+                return c->fail(PTGPU_E_HIP, "mesh %u: %s", i, err.c_str());
+        } else {
+            pth::build_mesh_tree(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf, naive, tree);
+        }
         if (all_tris.size() + tree.tris.size() >= (1ull << 31) - 2 || all_nodes.size() + tree.nodes.size() >= (1ull << 31))
             return c->fail(PTGPU_E_INVALID, "scene exceeds 2^31 triangles or nodes");
         pth::relocate(tree, static_cast<uint32_t>(all_nodes.size()), static_cast<uint32_t>(all_tris.size()));

@@ -39,7 +39,7 @@ struct fmat4x4 {  // column-major, m[c] is column c (glm layout)
 inline fvec3 xyz(const fvec4& v) { return fvec3{v.x, v.y, v.z}; }
 
 enum class RayProgramMode { RayCaster, AmbientOcclusion, PBR, kNum };   // src/arguments.h:10-16
-enum class AccelerationStructureType { Naive, BVH, kNum };              // src/arguments.h:18-23
+enum class AccelerationStructureType { Naive, BVH, DeviceLBVH, kNum };  // src/arguments.h:18-23 + the GPU-built tree (additive)
 enum class DefaultEnvironment { Black, White };
 
 struct RenderSettings {  // src/render_settings.h:7-21

@@ -1,7 +1,7 @@
 // PathTracer — command line of the reference (src/main.cc:12-62, src/arguments.cc:28-147) above the GPU renderer.
 // Same flags, defaults, stdout lines and exit codes; -f takes glTF 2.0 (.glb / .gltf) or the flat scene container.
 // Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw ptgpu_hit records,
-// row-major), --stats and --single-path (PBR keeps one ray per hit, chosen in proportion to its payload).
+// row-major), --stats, -a 3 (per-mesh trees built on the GPU) and --single-path (PBR keeps one ray per hit, chosen in proportion to its payload).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,7 +23,7 @@ struct Args {
 };
 
 const char* kUsage =
-    "Usage: PathTracer -f <scene.glb|.gltf|.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2]\n"
+    "Usage: PathTracer -f <scene.glb|.gltf|.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2|3]\n"
     "                  [-s samples] [-b bounces] [-r newrays] [--env_rot degrees] [-m max_leaf_triangles]\n"
     "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats] [--single-path]\n"
     "Use -h or --help for usage info.\n";
@@ -61,7 +61,7 @@ bool parse(int argc, char** argv, Args& a) {
         else { std::cerr << "unknown argument " << k << "\n" << kUsage; return false; }
     }
     if (a.model.empty()) { std::cerr << "-f is required\n" << kUsage; return false; }
-    if (a.program < 1 || a.program > 3 || a.as < 1 || a.as > 2 || a.samples < 1 || a.bounces < 0 || a.newrays < 0 || a.max_leaf < 1 ||
+    if (a.program < 1 || a.program > 3 || a.as < 1 || a.as > 3 || a.samples < 1 || a.bounces < 0 || a.newrays < 0 || a.max_leaf < 1 ||
         a.width < 1 || a.height < 1) {
         std::cerr << "argument out of range\n" << kUsage;
         return false;

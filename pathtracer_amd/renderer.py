@@ -28,6 +28,7 @@ class RayProgramMode(IntEnum):  # src/arguments.h:10-16
 class AccelerationStructureType(IntEnum):  # src/arguments.h:18-23
     Naive = 0
     BVH = 1
+    DeviceLBVH = 2  # not in the reference: per-mesh trees built on the GPU (fast load, somewhat slower traversal)
 
 
 @dataclass(frozen=True)
