@@ -237,7 +237,7 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
-    const uint64_t cap_limit = (24ull << 30) / 48;  // at most 24 GiB per pool; the scheduler splits segments beyond that
+    const uint64_t cap_limit = (32ull << 30) / 48;  // at most 32 GiB per pool; the scheduler splits segments beyond that
     cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
     for (Pool& p : c->pools) {
         if (p.cap < cap) {
@@ -356,17 +356,26 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     const uint64_t dump_launch = std::getenv("PTGPU_DUMP_LAUNCH") ? std::strtoull(std::getenv("PTGPU_DUMP_LAUNCH"), nullptr, 10) : 0;
     std::vector<Frame> frames;
     float ms = 0.0f;
+    const bool verbose_launches = std::getenv("PTGPU_VERBOSE") && std::atoi(std::getenv("PTGPU_VERBOSE")) >= 2;
+    // A generation that has shrunk to a sliver (the alpha pass-through chains at the end of a batch: a handful of
+    // launches of a few thousand rays each) is not worth launches of its own while another batch follows: it stays in
+    // its pool and the next batch's camera rays go on top of it.  Rays carry their own depth, so generations may mix.
+    const uint64_t carry_below = K / 32;
+    int gen_pool = 0;  // pool that receives the next batch's camera rays (the one holding carried rays, if any)
+    c->pools[0].top = c->pools[1].top = 0;
     for (uint64_t first = 0; first < total; first += K) {
         const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
-        c->pools[0].top = c->pools[1].top = 0;
+        const bool last_batch = first + K >= total;
+        Pool& gp = c->pools[gen_pool];
+        if (gp.top + n_gen > gp.cap) return c->fail(PTGPU_E_NOMEM, "ray pool too small for a batch of camera rays");
         PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
         PT_HIP(c, hipEventRecord(c->ev[0], st));
         if (slots_per_batch) {
             const uint32_t slot0 = static_cast<uint32_t>(first / per_slot);
             ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, slot0, n_gen,
-                                 static_cast<uint32_t>(n_gen / per_slot), c->pools[0].at(0), d_count);
+                                 static_cast<uint32_t>(n_gen / per_slot), gp.at(gp.top), d_count);
         } else {
-            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, c->pools[0].at(0),
+            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, gp.at(gp.top),
                                  d_count);
         }
         PT_HIP(c, hipEventRecord(c->ev[1], st));
@@ -376,9 +385,9 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.generate_ms += ms;
         const uint32_t n_cam = *c->host_counter;
         out.camera_samples += n_cam;
-        if (!n_cam) continue;
-        c->pools[0].top = n_cam;
-        frames.assign(1, Frame{0, 0, 0});
+        gp.top += n_cam;
+        if (!gp.top) continue;
+        frames.assign(1, Frame{gen_pool, 0, 0});
 
         while (!frames.empty()) {
             const Frame f = frames.back();
@@ -386,7 +395,13 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             Pool& op = c->pools[f.pool ^ 1];
             if (in.top <= f.floor_in) {  // generation consumed: drain what it spawned
                 frames.pop_back();
-                if (op.top > f.floor_out) frames.push_back({f.pool ^ 1, f.floor_out, f.floor_in});
+                if (op.top > f.floor_out) {
+                    if (!last_batch && frames.empty() && op.top < carry_below) {
+                        gen_pool = f.pool ^ 1;  // carried into the next batch (only ever the whole remainder of this one)
+                        break;
+                    }
+                    frames.push_back({f.pool ^ 1, f.floor_out, f.floor_in});
+                }
                 continue;
             }
             uint64_t n64 = std::min<uint64_t>(L, in.top - f.floor_in);
@@ -405,6 +420,10 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             }
             const uint32_t n = static_cast<uint32_t>(n64);
             const uint64_t offset = in.top - n;
+            if (verbose_launches)
+                std::fprintf(stderr, "[ptgpu] launch %llu: %u rays from pool %d (live %llu + %llu, depth of schedule %zu)\n",
+                             static_cast<unsigned long long>(out.extend_launches), n, f.pool, static_cast<unsigned long long>(in.top),
+                             static_cast<unsigned long long>(op.top), frames.size());
             const ptd::RayQueue rq = in.at(offset);
             if (dump_path && out.extend_launches == dump_launch) {  // developer aid: one launch's rays as raw float4 o[n], d[n]
                 std::vector<float4> buf(2ull * n);
