@@ -234,7 +234,7 @@ def main() -> None:
                 "scene_load_s": round(t_load, 2),
             },
         }
-        if world == 1 and not args.no_roofline:
+        if not args.no_roofline:  # rank 0's own launches (every rank holds the same scene)
             # Algorithmic bytes of the traversal kernel (the dominant one), counted on the same scene and camera at
             # reduced spp: per ray it reads origin + direction (32 B) and its candidate list (8 B per entered instance
             # plus the terminator), a 128 B transform per entered instance, 64 B per visited node and 48 B per tested

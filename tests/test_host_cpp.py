@@ -101,6 +101,18 @@ def test_cli_matches_python_mirror(tmp_path):
     scale = np.maximum(img[..., :3].max(axis=-1, keepdims=True), 1e-6)
     assert np.abs(got[..., :3] - img[..., :3]).max() <= (scale / 100.0).max()
     assert (np.abs(got[..., :3] - img[..., :3]) <= scale / 100.0).all()
+    # the two additive switches: trees built on the GPU and the single-path estimator (hit dump: ray caster records)
+    r = run("-f", scene, "-p", 3, "-a", 3, "-s", 16, "-b", 5, "--single-path", "--width", w, "--height", h, "--seed", 9, "-o", hdr,
+            "--dump-hits", hits_path, "--stats")
+    assert r.returncode == 0, r.stderr
+    g = H.make_gpu(model, None, H.settings(program=2, spp=16, bounces=5, seed=9, as_type=2, single=True), w, h)
+    img, st = H.gpu_render(g, w, h)
+    assert f"rays {st.rays} " in r.stdout
+    got = image_io.load_hdr(str(hdr))
+    scale = np.maximum(img[..., :3].max(axis=-1, keepdims=True), 1e-6)
+    assert (np.abs(got[..., :3] - img[..., :3]) <= scale / 100.0).all()
+    exact, _ = H.hits_equal(g.render_hits(w, h), np.fromfile(hits_path, dtype=abi.HIT_DTYPE).reshape(h, w))
+    assert exact.all()
 
 
 @needs_cli
