@@ -108,6 +108,8 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--single-path", action="store_true", help="PBR: one spawned ray per hit (same expectation)")
+    ap.add_argument("--binary-nodes", action="store_true",
+                    help="traverse the binary nodes in the reference's visiting order instead of the four-wide quantised nodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -152,7 +154,7 @@ def main() -> None:
     from pathtracer_amd.distributed import combine_partial_sums, subset_settings
     settings = subset_settings(RenderSettings(cfg["spp"], cfg["bounces"], cfg["newrays"], 8, 0.0,
                                               RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
-                                              singlePath=bool(cfg.get("single"))),
+                                              singlePath=bool(cfg.get("single")), wideNodes=not args.binary_nodes),
                                rank, world)
     r = Renderer(device_index)
     r.set_render_settings(settings)
@@ -228,6 +230,7 @@ def main() -> None:
             "config": {
                 "workload": f"{args.config}: program={RayProgramMode(cfg['program']).name} BVH {w}x{h} {cfg['spp']}spp "
                             f"{cfg['bounces']} bounces{' single-path' if cfg.get('single') else ''}, "
+                            f"{'binary' if args.binary_nodes else 'four-wide quantised'} nodes, "
                             f"{model.instanced_triangles()} instanced triangles, "
                             f"{len(model.objects)} objects",
                 "parallelism": f"sample-split x{world}" + ((" + RCCL" if backend == "nccl" else f" + {backend}") + " reduce(sum) to rank 0" if world > 1 else ""),
@@ -237,12 +240,12 @@ def main() -> None:
         if not args.no_roofline:  # rank 0's own launches (every rank holds the same scene)
             # Algorithmic bytes of the traversal kernel (the dominant one), counted on the same scene and camera at
             # reduced spp: per ray it reads origin + direction (32 B) and its candidate list (8 B per entered instance
-            # plus the terminator), a 128 B transform per entered instance, 64 B per visited node and 48 B per tested
-            # triangle, and writes a 20 B hit record.  The instance pass before it (tlas_kernel) reads 32 B + 64 B per
+            # plus the terminator), a 128 B transform per entered instance, 64 B per visited node (binary: two children's
+            # boxes; four-wide: four children's quantised boxes) and 48 B per tested triangle, and writes a 20 B hit record.  The instance pass before it (tlas_kernel) reads 32 B + 64 B per
             # tested instance bound and writes the candidate list; it is timed inside extend_ms but not in traverse_ms.
             count_settings = RenderSettings(min(cfg["spp"], 8), cfg["bounces"], cfg["newrays"], 8, 0.0,
                                             RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
-                                            singlePath=bool(cfg.get("single")))
+                                            singlePath=bool(cfg.get("single")), wideNodes=not args.binary_nodes)
             r.set_render_settings(count_settings)
             _, cst = r.render_counted(w, h)
             r.set_render_settings(settings)
@@ -258,15 +261,16 @@ def main() -> None:
             # this same command, tools/profile_bench.sh): bytes per ray of that run x the rays of one launch here.
             # FETCH_SIZE is taken as reported: the kernel reads random 64-byte sectors, for which the counter is exact
             # (tools/micro/calibrate_fetch.sh); the doubling rule applies to streaming 128-byte requests only.
+            kernel_name = "traverse_kernel<false, false>" if args.binary_nodes else "traverse_kernel<false, true>"
             traffic = None
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
-                k = tj.get("kernels", {}).get("traverse_kernel<false>")
+                k = tj.get("kernels", {}).get(kernel_name)
                 if k and tj.get("workload") == line["config"]["workload"]:
                     traffic = round((k["fetch_bytes_per_ray"] + k["write_bytes_per_ray"]) * rays / max(extend_launches, 1))
             line["roofline"] = {
-                "kernel": "traverse_kernel<false>",
+                "kernel": kernel_name,
                 "bound": "hbm",
                 "achieved": round(achieved, 2),
                 "peak": 8000.0,

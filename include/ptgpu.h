@@ -151,6 +151,14 @@ typedef struct ptgpu_settings {
  * at most one ray per hit, so deep bounce limits stay affordable. */
 #define PTGPU_FLAG_SINGLE_PATH 1u
 
+/* Read by ptgpu_load_scene; no counterpart in the reference.  The persistent traversal kernel walks a four-wide,
+ * quantised form of the same trees (inner children pulled up into their parent; child boxes stored with 8 bits per
+ * plane inside the parent's box, rounded outwards; 64 bytes for four children): about half the node visits and half
+ * the node bytes per ray.  The closest hit does not depend on the order in which boxes are visited, so hit records,
+ * ray counts and images are those of the binary tree except where two triangles tie in distance; what does depend on
+ * the order — WHICH triangle an any-hit ray reports, and the node-visit counters — differs from the reference. */
+#define PTGPU_FLAG_WIDE_NODES 2u
+
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */
 typedef struct ptgpu_hit {

@@ -91,6 +91,7 @@ class Settings(C.Structure):
 
 
 FLAG_SINGLE_PATH = 1
+FLAG_WIDE_NODES = 2
 
 
 class Hit(C.Structure):

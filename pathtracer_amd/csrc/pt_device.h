@@ -44,6 +44,16 @@ struct alignas(16) NodeQ {        // 64 B
     uint32_t left, right;
     uint32_t pad0, pad1;
 };
+// Four-wide node (optional form of the same trees): a binary node with inner children pulled up, its children's boxes
+// quantised to 8 bits per plane inside the node's own box — 64 B for four children instead of 64 B for two.
+// Plane value = origin[a] + scale[a] * q; a child's low planes are rounded down, its high planes up, so the stored box
+// contains the exact one.  Byte k of qlo[a] / qhi[a] belongs to child k; unused slots have ref PT_NO_NODE.
+struct alignas(64) Node4 {
+    float origin[3];
+    float scale[3];
+    uint32_t qlo[3], qhi[3];
+    uint32_t ref[4];
+};
 struct alignas(16) TriQ {         // 48 B
     float p1[3], e1[3], e2[3];    // e1 = p2 - p1, e2 = p3 - p1 (the first two operations of the triangle test)
     uint32_t index;
@@ -62,7 +72,8 @@ struct alignas(16) DevXform {     // 128 B
     uint32_t cull;                // 1 = back-face culling (mesh is not double sided)
     uint32_t object_index;
     uint32_t mesh_index;
-    uint32_t pad[4];
+    uint32_t root4;               // root reference into SceneDev::nodes4 (when the scene has four-wide nodes)
+    uint32_t pad[3];
 };
 struct DevTexture {               // 12 B; width 0 = the material has no such texture
     int32_t width, height;
@@ -101,6 +112,8 @@ struct SceneDev {
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)
     uint32_t n_instances;
     uint32_t n_top_nodes;         // nodes[0 .. n_top_nodes) are the most visited ones (kept in LDS by the traversal kernel)
+    const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
+    uint32_t n_top_nodes4;        // likewise for nodes4
     int32_t env_w, env_h;
     float env_rot;
 };

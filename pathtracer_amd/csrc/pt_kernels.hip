@@ -334,6 +334,12 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_BURST
 #define PT_BURST 8
 #endif
+#ifndef PT_WIDE_SORT
+#define PT_WIDE_SORT 2
+#endif
+#ifndef PT_WIDE_BURST
+#define PT_WIDE_BURST PT_BURST
+#endif
 #ifdef PT_NO_UNROLL
 #define PT_BURST_UNROLL _Pragma("unroll 1")
 #else
@@ -449,7 +455,7 @@ __device__ __forceinline__ float box_entry_fast(float lox, float loy, float loz,
 
 enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u };
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                  const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                  float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
@@ -465,8 +471,12 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t gthread = blockIdx.x * kBlock + tid;  // owner of one spill column
     TraceCount cnt{};
-    const uint32_t n_top = sc.n_top_nodes;
-    for (uint32_t i = tid; i < n_top * 4u; i += kBlock) s_top[i] = reinterpret_cast<const float4*>(sc.nodes)[i];
+    static_assert(kTopNodes4 <= kTopNodes && sizeof(Node4) == sizeof(NodeQ), "the four-wide node cache fits the same LDS array");
+    const uint32_t n_top = WIDE ? sc.n_top_nodes4 : sc.n_top_nodes;
+    {
+        const float4* src = WIDE ? reinterpret_cast<const float4*>(sc.nodes4) : reinterpret_cast<const float4*>(sc.nodes);
+        for (uint32_t i = tid; i < n_top * 4u; i += kBlock) s_top[i] = src[i];
+    }
     __syncthreads();
 
     // ---- per-lane state ----
@@ -599,13 +609,95 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                 if (!finite) flags |= F_SLOW;
                 h_t = kInfF; h_A = 0.0f; h_B = 0.0f; h_tri = 0; h_hit = false; h_back = false;
                 sp = 0;
-                cur = xf.root;
+                cur = WIDE ? xf.root4 : xf.root;
             }
         } else if (n_inner && n_inner >= n_leaf) {
             // ================= inner-node steps for the lanes that hold a node =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
-                if (is_node(cur)) {
+                if (WIDE && is_node(cur)) {
+                    if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
+                    const float4* np;
+                    if (cur < n_top) {
+                        if (COUNT) ++cnt.inst_tested;
+                        np = s_top + cur * 4u;
+                    } else {
+                        np = reinterpret_cast<const float4*>(sc.nodes4 + cur);
+                    }
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], rr = np[3];
+                    const uint32_t top = peek();
+                    // planes: origin + scale * q.  With the ray folded in, a plane's distance is A + q * B per axis.
+                    const uint32_t lqx = __float_as_uint(q1.z), lqy = __float_as_uint(q1.w), lqz = __float_as_uint(q2.x);
+                    const uint32_t hqx = __float_as_uint(q2.y), hqy = __float_as_uint(q2.z), hqz = __float_as_uint(q2.w);
+                    float d0, d1, d2, d3;
+                    if (!(flags & F_SLOW)) {
+                        const float ax = (q0.x - o.x) * inv.x, ay = (q0.y - o.y) * inv.y, az = (q0.z - o.z) * inv.z;
+                        const float bx = q0.w * inv.x, by = q1.x * inv.y, bz = q1.y * inv.z;
+                        auto entry = [&](int k) {
+                            const int sh = 8 * k;
+                            const float lx = __builtin_fmaf(static_cast<float>((lqx >> sh) & 0xffu), bx, ax);
+                            const float hx = __builtin_fmaf(static_cast<float>((hqx >> sh) & 0xffu), bx, ax);
+                            const float ly = __builtin_fmaf(static_cast<float>((lqy >> sh) & 0xffu), by, ay);
+                            const float hy = __builtin_fmaf(static_cast<float>((hqy >> sh) & 0xffu), by, ay);
+                            const float lz = __builtin_fmaf(static_cast<float>((lqz >> sh) & 0xffu), bz, az);
+                            const float hz = __builtin_fmaf(static_cast<float>((hqz >> sh) & 0xffu), bz, az);
+                            const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fminf(lz, hz));
+                            const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz));
+                            return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
+                        };
+                        d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
+                    } else {  // an infinite inverse direction: planes decoded, exact select forms
+                        auto entry = [&](int k) {
+                            const int sh = 8 * k;
+                            bool hh;
+                            float dd;
+                            box_test(q0.x + q0.w * static_cast<float>((lqx >> sh) & 0xffu), q0.y + q1.x * static_cast<float>((lqy >> sh) & 0xffu),
+                                     q0.z + q1.y * static_cast<float>((lqz >> sh) & 0xffu), q0.x + q0.w * static_cast<float>((hqx >> sh) & 0xffu),
+                                     q0.y + q1.x * static_cast<float>((hqy >> sh) & 0xffu), q0.z + q1.y * static_cast<float>((hqz >> sh) & 0xffu),
+                                     o, inv, hh, dd);
+                            return dd;
+                        };
+                        d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
+                    }
+                    uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
+                    // a child is a candidate when it exists and its box is entered nearer than the current hit
+                    d0 = (r0 != PT_NO_NODE && h_t > d0) ? d0 : kInfF;
+                    d1 = (r1 != PT_NO_NODE && h_t > d1) ? d1 : kInfF;
+                    d2 = (r2 != PT_NO_NODE && h_t > d2) ? d2 : kInfF;
+                    d3 = (r3 != PT_NO_NODE && h_t > d3) ? d3 : kInfF;
+                    auto order = [](float& da, uint32_t& ra, float& db, uint32_t& rb) {
+                        const bool swap = db < da;
+                        const float dn = swap ? db : da, df = swap ? da : db;
+                        const uint32_t rn = swap ? rb : ra, rf = swap ? ra : rb;
+                        da = dn; db = df; ra = rn; rb = rf;
+                    };
+#if PT_WIDE_SORT == 2
+                    order(d0, r0, d1, r1);
+                    order(d2, r2, d3, r3);
+                    order(d0, r0, d2, r2);
+                    order(d1, r1, d3, r3);
+                    order(d1, r1, d2, r2);
+#else  // the nearest child to the front, the others in slot order
+                    order(d0, r0, d1, r1);
+                    order(d2, r2, d3, r3);
+                    order(d0, r0, d2, r2);
+#endif
+                    auto push = [&](uint32_t ref) {
+                        if (sp < kStackLds) s_stack[sp][tid] = ref;
+                        else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
+                            spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = ref;
+                        ++sp;
+                    };
+                    if (d0 < kInfF) {  // nearest first; the others wait on the stack, the nearer the higher
+                        if (d3 < kInfF) push(r3);
+                        if (d2 < kInfF) push(r2);
+                        if (d1 < kInfF) push(r1);
+                        cur = r0;
+                    } else {
+                        pop_to(top);
+                    }
+                }
+                if (!WIDE && is_node(cur)) {
                     if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
                     float4 nx, ny, nz, nr;
                     if (cur < n_top) {  // from LDS: no work for the L1's address unit
@@ -644,7 +736,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                         pop_to(top);
                     }
                 }
-                if (++burst >= PT_BURST) { if (COUNT) tally(2, burst); break; }
+                if (++burst >= (WIDE ? PT_WIDE_BURST : PT_BURST)) { if (COUNT) tally(2, burst); break; }
                 const uint32_t still = __popcll(__ballot(is_node(cur)));
                 if (still * 2u < n_inner) { if (COUNT) tally(2, burst); break; }
             }
@@ -1426,7 +1518,7 @@ void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n
 }
 uint32_t extend_persistent_grid(int device) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false, false>, kBlock, 0) != hipSuccess || per_cu < 1)
         per_cu = 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(cus);
@@ -1443,15 +1535,23 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
     if (counters) {
         hipLaunchKernelGGL(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        hipLaunchKernelGGL(traverse_kernel<true>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
-                           spill_depth, stride, next_ray, overflow, counters);
+        if (sc.nodes4)
+            hipLaunchKernelGGL((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else
+            hipLaunchKernelGGL((traverse_kernel<true, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
         hipLaunchKernelGGL(extend_overflow_kernel<true>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
                            spill_depth, stride, counters);
     } else {
         hipLaunchKernelGGL(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        hipLaunchKernelGGL(traverse_kernel<false>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
-                           spill_depth, stride, next_ray, overflow, counters);
+        if (sc.nodes4)
+            hipLaunchKernelGGL((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else
+            hipLaunchKernelGGL((traverse_kernel<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
         // continuation of the rare rays with more candidate instances than the lists hold (returns at once when none)
         hipLaunchKernelGGL(extend_overflow_kernel<false>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
                            spill_depth, stride, counters);

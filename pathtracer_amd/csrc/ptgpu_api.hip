@@ -128,7 +128,7 @@ struct ptgpu_ctx {
     bool scene_loaded = false, camera_set = false;
 
     // scene
-    DevBuf nodes, tris, instances, xforms, objects, corners, texels, env, lut;
+    DevBuf nodes, nodes4, tris, instances, xforms, objects, corners, texels, env, lut;
     ptd::SceneDev scene{};
     std::vector<ptgpu_bvh_info> bvh_info;
     std::vector<uint32_t> object_mesh;  // object -> mesh index (for hit dumps)
@@ -581,7 +581,7 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
     if (!c || !s) return PTGPU_E_INVALID;
     if (s->program_mode < 0 || s->program_mode > 2 || s->accel_struct_type < 0 || s->accel_struct_type > 2)
         return c->fail(PTGPU_E_INVALID, "set_render_settings: program_mode / accel_struct_type out of range");
-    if (s->flags & ~PTGPU_FLAG_SINGLE_PATH) return c->fail(PTGPU_E_INVALID, "set_render_settings: unknown flag bits 0x%x", s->flags);
+    if (s->flags & ~(PTGPU_FLAG_SINGLE_PATH | PTGPU_FLAG_WIDE_NODES)) return c->fail(PTGPU_E_INVALID, "set_render_settings: unknown flag bits 0x%x", s->flags);
     c->settings = *s;
     return PTGPU_OK;
 }
@@ -717,6 +717,162 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
             if (!(xf.root & PT_LEAF_BIT)) xf.root = new_index[xf.root];
     }
 
+    // ---- optional four-wide nodes (PTGPU_FLAG_WIDE_NODES): inner children pulled up into their parent, largest box first ----
+    std::vector<ptd::Node4> wide;
+    uint32_t n_top4 = 0;
+    if ((s.flags & PTGPU_FLAG_WIDE_NODES) && c->persistent && !all_nodes.empty()) {
+        struct Child {
+            uint32_t ref;
+            float lo[3], hi[3];
+        };
+        auto half_area = [](const Child& ch) {
+            const float dx = ch.hi[0] - ch.lo[0], dy = ch.hi[1] - ch.lo[1], dz = ch.hi[2] - ch.lo[2];
+            return dx * dy + dx * dz + dy * dz;
+        };
+        auto children_of = [&](uint32_t node, Child out[2]) {
+            const ptd::DevNode& nd = all_nodes[node];
+            out[0].ref = nd.left;
+            out[1].ref = nd.right;
+            std::memcpy(out[0].lo, nd.l_lo, 12); std::memcpy(out[0].hi, nd.l_hi, 12);
+            std::memcpy(out[1].lo, nd.r_lo, 12); std::memcpy(out[1].hi, nd.r_hi, 12);
+        };
+        std::vector<uint32_t> wide_of(all_nodes.size(), PT_NO_NODE);  // binary node -> wide node made from it
+        std::vector<uint32_t> depth_of;                               // per wide node
+        uint32_t max_depth4 = 0;
+        struct Todo {
+            uint32_t binary, wide_index;
+        };
+        std::vector<Todo> todo;
+        auto make = [&](uint32_t binary, uint32_t depth) -> uint32_t {
+            const uint32_t w = static_cast<uint32_t>(wide.size());
+            wide.emplace_back();
+            depth_of.push_back(depth);
+            max_depth4 = std::max(max_depth4, depth);
+            wide_of[binary] = w;
+            todo.push_back({binary, w});
+            return w;
+        };
+        std::vector<uint32_t> mesh_root4(model->n_meshes, PT_NO_NODE);
+        std::vector<uint32_t> binary_root(model->n_meshes, PT_NO_NODE);
+        for (const ptd::DevXform& xf : table.xforms) binary_root[xf.mesh_index] = xf.root;
+        for (uint32_t m = 0; m < model->n_meshes; ++m) {
+            const uint32_t root = binary_root[m];
+            if (root == PT_NO_NODE) continue;  // mesh without an instance
+            if (root & PT_LEAF_BIT) {
+                mesh_root4[m] = root;
+                continue;
+            }
+            mesh_root4[m] = make(root, 1);
+            while (!todo.empty()) {
+                const Todo t = todo.back();
+                todo.pop_back();
+                Child ch[4];
+                int n_ch = 2;
+                children_of(t.binary, ch);
+                while (n_ch < 4) {  // pull up the inner child with the largest box
+                    int best = -1;
+                    float best_area = -1.0f;
+                    for (int k = 0; k < n_ch; ++k)
+                        if (!(ch[k].ref & PT_LEAF_BIT) && half_area(ch[k]) > best_area) {
+                            best_area = half_area(ch[k]);
+                            best = k;
+                        }
+                    if (best < 0) break;
+                    Child two[2];
+                    children_of(ch[best].ref, two);
+                    ch[best] = two[0];
+                    ch[n_ch++] = two[1];
+                }
+                ptd::Node4 nd;
+                std::memset(&nd, 0, sizeof(nd));
+                // the node's own box, and per axis the step that reaches its far side in 255 steps (plane = origin + step * q,
+                // evaluated in binary32 as the kernel's slow path does; low planes round down, high planes up)
+                for (int a = 0; a < 3; ++a) {
+                    float lo = ch[0].lo[a], hi = ch[0].hi[a];
+                    for (int k = 1; k < n_ch; ++k) {
+                        lo = std::min(lo, ch[k].lo[a]);
+                        hi = std::max(hi, ch[k].hi[a]);
+                    }
+                    float step = (hi - lo) / 255.0f;
+                    if (!(step > 0.0f) || !(step < std::numeric_limits<float>::max())) step = 0.0f;
+                    while (step > 0.0f && lo + step * 255.0f < hi) step = std::nextafter(step, std::numeric_limits<float>::max());
+                    nd.origin[a] = lo;
+                    nd.scale[a] = step;
+                    for (int k = 0; k < n_ch; ++k) {
+                        int ql = 0, qh = 0;
+                        if (step > 0.0f) {
+                            ql = std::clamp(static_cast<int>(std::floor((ch[k].lo[a] - lo) / step)), 0, 255);
+                            while (ql > 0 && lo + step * static_cast<float>(ql) > ch[k].lo[a]) --ql;
+                            qh = std::clamp(static_cast<int>(std::ceil((ch[k].hi[a] - lo) / step)), 0, 255);
+                            while (qh < 255 && lo + step * static_cast<float>(qh) < ch[k].hi[a]) ++qh;
+                        }
+                        nd.qlo[a] |= static_cast<uint32_t>(ql) << (8 * k);
+                        nd.qhi[a] |= static_cast<uint32_t>(qh) << (8 * k);
+                    }
+                }
+                for (int k = 0; k < 4; ++k)
+                    nd.ref[k] = (k >= n_ch) ? PT_NO_NODE
+                                            : ((ch[k].ref & PT_LEAF_BIT) ? ch[k].ref : make(ch[k].ref, depth_of[t.wide_index] + 1));
+                wide[t.wide_index] = nd;
+            }
+        }
+        for (ptd::DevXform& xf : table.xforms) xf.root4 = mesh_root4[xf.mesh_index];
+        // the most visited wide nodes first (same estimate as for the binary nodes), kept in LDS by the kernel
+        {
+            std::vector<float> mesh_weight(model->n_meshes, 0.0f);
+            for (const ptd::DevXform& xf : table.xforms) {
+                const float* m = xf.model;
+                const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[3] * (m[1] * m[8] - m[2] * m[7]) + m[6] * (m[1] * m[5] - m[2] * m[4]);
+                const float scale = std::cbrt(std::fabs(det));
+                mesh_weight[xf.mesh_index] += scale * scale;
+            }
+            struct Entry {
+                float priority;
+                uint32_t node, mesh;
+                bool operator<(const Entry& o) const { return priority < o.priority; }
+            };
+            std::priority_queue<Entry> queue;
+            for (uint32_t m = 0; m < model->n_meshes; ++m)
+                if (mesh_root4[m] != PT_NO_NODE && !(mesh_root4[m] & PT_LEAF_BIT) && mesh_weight[m] > 0.0f)
+                    queue.push({std::numeric_limits<float>::max(), mesh_root4[m], m});
+            std::vector<uint32_t> order;
+            while (!queue.empty() && order.size() < static_cast<size_t>(ptd::kTopNodes4)) {
+                const Entry e = queue.top();
+                queue.pop();
+                order.push_back(e.node);
+                const ptd::Node4& nd = wide[e.node];
+                for (int k = 0; k < 4; ++k)
+                    if (nd.ref[k] != PT_NO_NODE && !(nd.ref[k] & PT_LEAF_BIT)) {
+                        float ext[3];
+                        for (int a = 0; a < 3; ++a)
+                            ext[a] = nd.scale[a] * static_cast<float>(static_cast<int>((nd.qhi[a] >> (8 * k)) & 0xffu) -
+                                                                      static_cast<int>((nd.qlo[a] >> (8 * k)) & 0xffu));
+                        queue.push({(ext[0] * ext[1] + ext[0] * ext[2] + ext[1] * ext[2]) * mesh_weight[e.mesh], nd.ref[k], e.mesh});
+                    }
+            }
+            n_top4 = static_cast<uint32_t>(order.size());
+            std::vector<uint32_t> new_index(wide.size(), PT_NO_NODE);
+            for (uint32_t k = 0; k < n_top4; ++k) new_index[order[k]] = k;
+            uint32_t next = n_top4;
+            for (uint32_t i = 0; i < wide.size(); ++i)
+                if (new_index[i] == PT_NO_NODE) new_index[i] = next++;
+            std::vector<ptd::Node4> moved(wide.size());
+            for (uint32_t i = 0; i < wide.size(); ++i) {
+                ptd::Node4 n = wide[i];
+                for (int k = 0; k < 4; ++k)
+                    if (n.ref[k] != PT_NO_NODE && !(n.ref[k] & PT_LEAF_BIT)) n.ref[k] = new_index[n.ref[k]];
+                moved[new_index[i]] = n;
+            }
+            wide.swap(moved);
+            for (ptd::DevXform& xf : table.xforms)
+                if (xf.root4 != PT_NO_NODE && !(xf.root4 & PT_LEAF_BIT)) xf.root4 = new_index[xf.root4];
+        }
+        // a visit pushes up to three children: the stack can hold 3 entries per level
+        c->max_depth = std::max(c->max_depth, 3u * max_depth4 + 1u);
+        if (std::getenv("PTGPU_VERBOSE"))
+            std::fprintf(stderr, "[ptgpu] four-wide nodes: %zu (from %zu binary), depth %u\n", wide.size(), all_nodes.size(), max_depth4);
+    }
+
     // ---- shading data ----
     // corners: every triangle's three vertices de-indexed, in mesh order (the hit record's triangle index / 3)
     std::vector<uint64_t> mesh_tri_base(model->n_meshes);
@@ -829,6 +985,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     int rc;
     if ((rc = upload(c, c->nodes, q_nodes.data(), q_nodes.size()))) return rc;
     if ((rc = upload(c, c->tris, q_tris.data(), q_tris.size()))) return rc;
+    if (!wide.empty() && (rc = upload(c, c->nodes4, wide.data(), wide.size()))) return rc;
     if ((rc = upload(c, c->instances, table.instances.data(), table.instances.size()))) return rc;
     if ((rc = upload(c, c->xforms, table.xforms.data(), table.xforms.size()))) return rc;
     if ((rc = upload(c, c->objects, objects.data(), objects.size()))) return rc;
@@ -849,6 +1006,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.srgb_lut = c->lut.as<float>();
     sc.n_instances = static_cast<uint32_t>(table.instances.size());
     sc.n_top_nodes = n_top;
+    sc.nodes4 = wide.empty() ? nullptr : c->nodes4.as<ptd::Node4>();
+    sc.n_top_nodes4 = n_top4;
     sc.env_w = env_w;
     sc.env_h = env_h;
     sc.env_rot = s.envmap_rotation;

@@ -416,7 +416,7 @@ void Renderer::push_settings() {
     s.seed = seed_;
     s.sample_begin = 0;
     s.sample_step = 1;
-    s.flags = single_path_ ? PTGPU_FLAG_SINGLE_PATH : 0u;
+    s.flags = (single_path_ ? PTGPU_FLAG_SINGLE_PATH : 0u) | (wide_nodes_ ? PTGPU_FLAG_WIDE_NODES : 0u);
     const int rc = ptgpu_set_render_settings(ctx_, &s);
     if (rc != PTGPU_OK) fail("ptgpu_set_render_settings", rc);
 }
@@ -516,10 +516,11 @@ std::vector<ptgpu_hit> Renderer::render_hits(int width, int height, uint32_t sam
 // ---------------------------------------------------------------------------------------------
 // Viewer (src/viewer.cc)
 // ---------------------------------------------------------------------------------------------
-Viewer::Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device)
+Viewer::Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device, bool wide_nodes)
     : model_(std::move(model)), environmentTexture_(std::move(environmentTexture)), renderer_(device) {
     if (!model_.cameras_.empty()) activeCameraIndex_ = 0;
     framebuffer_ = CPUFrameBuffer(windowDimensions_.x, windowDimensions_.y);
+    renderer_.set_wide_nodes(wide_nodes);
     renderer_.set_render_settings(settings);
     renderer_.load_scene(model_, environmentTexture_);
     if (!snap_to_camera()) {

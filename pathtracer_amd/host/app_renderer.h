@@ -33,6 +33,7 @@ class Renderer {
     // additions of the GPU build
     void set_seed(uint32_t seed) { seed_ = seed; push_settings(); }
     void set_single_path(bool on) { single_path_ = on; push_settings(); }  // PTGPU_FLAG_SINGLE_PATH
+    void set_wide_nodes(bool on) { wide_nodes_ = on; push_settings(); }    // PTGPU_FLAG_WIDE_NODES, takes effect at load_scene
     const ptgpu_stats& last_stats() const { return stats_; }
     // closest hit of sample `sample` of every pixel, row-major (the raycast parity dump)
     std::vector<ptgpu_hit> render_hits(int width, int height, uint32_t sample = 0);
@@ -44,13 +45,14 @@ class Renderer {
     ptgpu_ctx* ctx_ = nullptr;
     RenderSettings renderSettings_;
     uint32_t seed_ = 0;
-    bool single_path_ = false;
+    bool single_path_ = false, wide_nodes_ = false;
     ptgpu_stats stats_{};
 };
 
 class Viewer {  // src/viewer.h: owns model, environment, renderer and framebuffer
   public:
-    Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device = 0);
+    Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device = 0,
+           bool wide_nodes = false);  // wide_nodes: Renderer::set_wide_nodes before the scene is loaded
     void resize_window(const ivec2& newDimensions);
     ivec2 get_window_dimensions() const { return windowDimensions_; }
     void render() { renderer_.render_frame(framebuffer_); }

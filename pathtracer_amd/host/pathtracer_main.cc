@@ -1,7 +1,7 @@
 // PathTracer — command line of the reference (src/main.cc:12-62, src/arguments.cc:28-147) above the GPU renderer.
 // Same flags, defaults, stdout lines and exit codes; -f takes glTF 2.0 (.glb / .gltf) or the flat scene container.
 // Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw ptgpu_hit records,
-// row-major), --stats, -a 3 (per-mesh trees built on the GPU) and --single-path (PBR keeps one ray per hit, chosen in proportion to its payload).
+// row-major), --stats, -a 3 (per-mesh trees built on the GPU), --wide-nodes (four-wide quantised nodes) and --single-path (PBR keeps one ray per hit, chosen in proportion to its payload).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -19,13 +19,13 @@ struct Args {
     int program = 3, as = 2, samples = 1, bounces = 4, newrays = 0, env_rot = 0, max_leaf = 8, width = 800, height = 600;
     unsigned seed = 0;
     int device = 0;
-    bool stats = false, single_path = false;
+    bool stats = false, single_path = false, wide_nodes = false;
 };
 
 const char* kUsage =
     "Usage: PathTracer -f <scene.glb|.gltf|.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2|3]\n"
     "                  [-s samples] [-b bounces] [-r newrays] [--env_rot degrees] [-m max_leaf_triangles]\n"
-    "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats] [--single-path]\n"
+    "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats] [--single-path] [--wide-nodes]\n"
     "Use -h or --help for usage info.\n";
 
 bool parse(int argc, char** argv, Args& a) {
@@ -58,6 +58,7 @@ bool parse(int argc, char** argv, Args& a) {
         else if (k == "--seed") { if (!(v = need(i))) return false; a.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10)); }
         else if (k == "--stats") { a.stats = true; }
         else if (k == "--single-path") { a.single_path = true; }
+        else if (k == "--wide-nodes") { a.wide_nodes = true; }
         else { std::cerr << "unknown argument " << k << "\n" << kUsage; return false; }
     }
     if (a.model.empty()) { std::cerr << "-f is required\n" << kUsage; return false; }
@@ -105,7 +106,7 @@ int main(int argc, char* argv[]) {
         settings.programMode = static_cast<RayProgramMode>(args.program - 1);
         settings.accelStructType = static_cast<AccelerationStructureType>(args.as - 1);
 
-        Viewer viewer(std::move(model), std::move(environment_texture), settings, args.device);
+        Viewer viewer(std::move(model), std::move(environment_texture), settings, args.device, args.wide_nodes);
         viewer.renderer().set_seed(args.seed);
         viewer.renderer().set_single_path(args.single_path);
         viewer.resize_window(ivec2{args.width, args.height});

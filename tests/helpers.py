@@ -10,9 +10,9 @@ from oracle import binding as ob
 
 
 def settings(program=2, spp=1, bounces=4, newrays=0, as_type=1, leaf=8, seed=1234, env_rot=0.0, begin=0, step=1,
-             single=False):
+             single=False, wide=False):
     return RenderSettings(spp, bounces, newrays, leaf, env_rot, RayProgramMode(program),
-                          AccelerationStructureType(as_type), seed, begin, step, single)
+                          AccelerationStructureType(as_type), seed, begin, step, single, wide)
 
 
 def make_oracle(model, env, st: RenderSettings, width, height, math_mode=ob.MATH_PORTABLE, rng_mode=ob.RNG_COUNTER):

@@ -227,6 +227,50 @@ def test_device_built_tree_gives_the_same_hits(tiny, scene):
     assert (occluded_g == occluded_o).mean() >= 0.9999
 
 
+@pytest.mark.parametrize("scene,as_type", [("tiny", 1), ("readme", 1), ("materials", 1), ("mesh", 2)])
+def test_wide_nodes_give_the_same_results(tiny, materials, scene, as_type):
+    """Four-wide quantised nodes (PTGPU_FLAG_WIDE_NODES) over the host-built and the device-built trees: the boxes are
+    visited in another order and are slightly larger, the triangles and their tests are the same, so closest hits do not
+    change.  Against the oracle (binary tree, the reference's order): primary-hit records bit-identical (>= 99.99 %
+    required, ties in distance excepted), equal ray counts and PBR pixels within 2e-5 * max(1, value), ambient-occlusion
+    frames (any-hit rays: only hit / miss matters) equal to the binary nodes' to the bit, any-hit flags of random rays equal; and fewer node visits."""
+    model, env = {"tiny": tiny, "materials": materials, "readme": (scenes.readme_standin(detail=0.05), scenes.synthetic_env()),
+                  "mesh": (scenes.stress_mesh(300_000), None)}[scene]
+    w, h = 320, 180
+    st = H.settings(program=2, spp=2, bounces=4, as_type=as_type, wide=True)
+    g = H.make_gpu(model, env, st, w, h)
+    o = H.make_oracle(model, env, H.settings(program=2, spp=2, bounces=4), w, h)
+    exact, _ = H.hits_equal(o.render_hits(w, h), g.render_hits(w, h))
+    assert exact.mean() >= 0.9999, f"{(~exact).sum()} of {w * h} primary-hit records differ"
+    img_o, so = o.render_frame(w, h)
+    img_g, sg = g.render_counted(w, h)
+    if as_type == 1:
+        assert exact.all() and sg.rays == so.rays
+        assert (np.abs(img_g[..., :3] - img_o[..., :3]) <= 2e-5 * np.maximum(1.0, np.abs(img_o[..., :3]))).all()
+        assert sg.triangles_tested >= so.triangles_tested
+    else:
+        assert abs(int(sg.rays) - int(so.rays)) <= 1e-4 * so.rays
+    assert sg.nodes_visited < 0.7 * so.nodes_visited
+    st_ao = H.settings(program=1, spp=4, bounces=1, newrays=8, as_type=as_type, wide=True)
+    g.set_render_settings(st_ao)
+    o_ao = H.make_oracle(model, None, H.settings(program=1, spp=4, bounces=1, newrays=8), w, h)
+    g_ao = H.make_gpu(model, None, st_ao, w, h)
+    ao_g, _ = H.gpu_render(g_ao, w, h)
+    ao_o, _ = o_ao.render_frame(w, h)
+    assert (np.abs(ao_g[..., :3] - ao_o[..., :3]) <= 2e-5).mean() >= 0.9999  # (the oracle's running mean rounds differently)
+    ao_b, _ = H.gpu_render(H.make_gpu(model, None, H.settings(program=1, spp=4, bounces=1, newrays=8, as_type=as_type), w, h), w, h)
+    assert (ao_g == ao_b).mean() >= 0.9999  # sums of multiples of 1/8 are exact: binary and wide nodes agree to the bit
+    rng = np.random.default_rng(11)
+    n = 20000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    flags = np.ones(n, np.uint8)
+    assert (g.intersect_rays(org, d, flags)["hit"] == o.intersect_rays(org, d, flags)["hit"]).mean() >= 0.9999
+    exact, _ = H.hits_equal(o.intersect_rays(org, d), g.intersect_rays(org, d))
+    assert exact.mean() >= 0.9999
+
+
 def test_golden_converged_images(tiny, golden):
     model, env = tiny
     w, h = 64, 36
@@ -348,6 +392,14 @@ def test_full_size_readme_frame_properties():
         parts.append(buf)
     both = ((parts[0] + parts[1])[..., :3] / 2).cpu().numpy()
     assert np.allclose(both, img[..., :3], rtol=1e-5, atol=1e-6)
+    # the same frame over four-wide nodes (the benchmark's setting): same rays, same band
+    gw = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=6, wide=True), w, h)
+    img_w, sw = H.gpu_render(gw, w, h)
+    assert sw.rays == s.rays
+    d = np.abs(img_w[292:308, :, :3] - band[292:308, :, :3])
+    assert (d <= 2e-5 * np.maximum(1.0, band[292:308, :, :3])).all(), d.max()
+    exact, _ = H.hits_equal(g.render_hits(w, h), gw.render_hits(w, h))
+    assert exact.all()
 
 
 def test_full_size_ambient_occlusion_properties():
