@@ -156,7 +156,9 @@ typedef struct ptgpu_settings {
  * plane inside the parent's box, rounded outwards; 64 bytes for four children): about half the node visits and half
  * the node bytes per ray.  The closest hit does not depend on the order in which boxes are visited, so hit records,
  * ray counts and images are those of the binary tree except where two triangles tie in distance; what does depend on
- * the order — WHICH triangle an any-hit ray reports, and the node-visit counters — differs from the reference. */
+ * the order — WHICH triangle an any-hit ray reports, and the node-visit counters — differs from the reference.
+ * Trees for this layout are built with leaves of at most 2 triangles (min(max_triangles_per_bvh_leaf, 2)): fewer
+ * triangle tests per ray.  Ignored with PTGPU_AS_NAIVE. */
 #define PTGPU_FLAG_WIDE_NODES 2u
 
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
