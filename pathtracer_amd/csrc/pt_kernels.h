@@ -9,9 +9,13 @@
 namespace ptd {
 
 constexpr int kBlock = 256;          // threads per workgroup: 4 wavefronts of 64 lanes
-constexpr int kStackLds = 16;        // per-lane traversal stack entries kept in LDS; deeper entries spill to HBM
-constexpr int kTopNodes = 224;       // BVH nodes every traversal workgroup keeps in LDS (14 KB)
-constexpr int kTopNodes4 = 224;      // likewise for the four-wide form (also 64 B a node)
+#ifndef PT_STACK_LDS
+#define PT_STACK_LDS 12
+#endif
+constexpr int kStackLds = PT_STACK_LDS;  // per-lane traversal stack entries kept in LDS; deeper entries spill to HBM
+constexpr int kTopNodes = 192;       // BVH nodes every traversal workgroup keeps in LDS (12 KB)
+constexpr uint32_t kXformLds = 16;   // instance transforms kept in LDS by the same kernel (2 KB)
+constexpr int kTopNodes4 = 192;      // likewise for the four-wide form (also 64 B a node)
 constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
 constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
 

@@ -466,6 +466,8 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     // The most visited nodes (the first of the node array), 64 bytes each, node after node.  Layouts that spread the
     // lanes' reads over more banks (quarter-major, 80-byte stride) measured 20-40 % slower for the whole kernel.
     __shared__ float4 s_top[kTopNodes * 4];
+    // the transforms of the first instances (128 B each): read once per instance a ray enters, and again per accepted hit
+    __shared__ float4 s_xf[kXformLds * (sizeof(DevXform) / 16)];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -476,8 +478,13 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     {
         const float4* src = WIDE ? reinterpret_cast<const float4*>(sc.nodes4) : reinterpret_cast<const float4*>(sc.nodes);
         for (uint32_t i = tid; i < n_top * 4u; i += kBlock) s_top[i] = src[i];
+        const uint32_t n_xf = (sc.n_instances < kXformLds ? sc.n_instances : kXformLds) * (sizeof(DevXform) / 16);
+        if (tid < n_xf) s_xf[tid] = reinterpret_cast<const float4*>(sc.xforms)[tid];
     }
     __syncthreads();
+    auto xform_record = [&](uint32_t k) -> const DevXform& {
+        return (k < kXformLds) ? reinterpret_cast<const DevXform*>(s_xf)[k] : sc.xforms[k];
+    };
 
     // ---- per-lane state ----
     // `cur` doubles as the lane's state: PT_IDLE = no ray, PT_NO_NODE = the ray needs its next instance,
@@ -546,7 +553,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     if ((__float_as_uint(rd.w) >> 8) & 1u) flags |= F_ANY;
                 } else if (h_hit) {
                     // back to a world-space distance and acceptance (acceleration_structure.cc:704-706, 616-623)
-                    const DevXform& xf = sc.xforms[slot];
+                    const DevXform& xf = xform_record(slot);
                     const f3 p = o + d * h_t;
                     const f3 p_ws = xform(xf.model, p, 1.0f);
                     const float t_ws = length3(p_ws - ow);
@@ -599,7 +606,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             if (enter_slot != PT_NO_NODE) {
                 if (COUNT) ++cnt.inst_entered;
                 slot = enter_slot;
-                const DevXform& xf = sc.xforms[slot];
+                const DevXform& xf = xform_record(slot);
                 o = xform(xf.inv, ow, 1.0f);
                 d = normalize3(xform(xf.inv, dw, 0.0f));
                 inv = f3{1.0f / d.x, 1.0f / d.y, 1.0f / d.z};
@@ -958,11 +965,20 @@ __device__ __forceinline__ Taps bilinear_taps(float u, float v, int w, int h) {
 // channel, the same binary32 value.
 __shared__ float s_srgb_lut[256];
 __shared__ float s_unorm_lut[256];
+// The first kObjLds object records (matrices + material, 256 B each) are read by nearly every hit: a copy in LDS takes
+// those reads (15 of a PBR hit's ~58 loads) off the vector memory path.
+constexpr uint32_t kObjLds = 16;
+__shared__ float4 s_objects[kObjLds * (sizeof(DevObject) / 16)];
 __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
     static_assert(kBlock == 256, "one table entry per thread");
     s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
     s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
+    const uint32_t n_quarters = (sc.n_instances < kObjLds ? sc.n_instances : kObjLds) * (sizeof(DevObject) / 16);
+    if (threadIdx.x < n_quarters) s_objects[threadIdx.x] = reinterpret_cast<const float4*>(sc.objects)[threadIdx.x];
     __syncthreads();
+}
+__device__ __forceinline__ const DevObject* object_record(const SceneDev& sc, uint32_t object) {
+    return (object < kObjLds) ? reinterpret_cast<const DevObject*>(s_objects) + object : sc.objects + object;
 }
 __device__ __forceinline__ float4 texel8(const SceneDev& sc, uint32_t word, bool srgb) {
     uint32_t r = word & 0xffu, g = (word >> 8) & 0xffu, b = (word >> 16) & 0xffu, a = word >> 24;
@@ -1093,7 +1109,7 @@ struct ShadePoint {
 // get_vertex_data + interpolate_vertex_data + convert_normals_to_world_space (ray_program.cc:75-101)
 __device__ __forceinline__ ShadePoint fetch_point(const SceneDev& sc, uint32_t object, uint32_t tri, float A, float B) {
     ShadePoint sp;
-    sp.obj = sc.objects + object;
+    sp.obj = object_record(sc, object);
     const float4* rec = sc.corners + static_cast<size_t>(sp.obj->tri_base + tri / 3u) * 9u;  // tri = 3 * triangle number
     const VertexD v1 = load_vertex(rec), v2 = load_vertex(rec + 3), v3 = load_vertex(rec + 6);
     const float C = 1.0f - A - B;
@@ -1166,7 +1182,7 @@ __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQ
         c = sample_environment(sc, ld3(rd));
     } else {
         const uint32_t object = h1 & 0x3fffffffu;
-        const DevObject* obj = sc.objects + object;
+        const DevObject* obj = object_record(sc, object);
         const float4* rec = sc.corners + static_cast<size_t>(obj->tri_base + __float_as_uint(h0.w) / 3u) * 9u;
         const float4 c1 = rec[2], c2 = rec[5], c3 = rec[8];
         const float A = h0.y, B = h0.z, C = 1.0f - A - B;

@@ -9,11 +9,12 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 prog = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 detail = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+wide = (int(sys.argv[5]) if len(sys.argv) > 5 else 1) != 0  # four-wide quantised nodes (what the benchmark runs)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 model = scenes.readme_standin(detail=detail)
 env = image_io.load_hdr(os.path.join(root, "assets", "farmland_overcast_1k.hdr"))
 w, h = 800, 600
-st = H.settings(program=prog, spp=spp, bounces=6 if prog == 2 else 1, newrays=8 if prog == 1 else 0)
+st = H.settings(program=prog, spp=spp, bounces=6 if prog == 2 else 1, newrays=8 if prog == 1 else 0, wide=wide)
 g = H.make_gpu(model, env, st, w, h)
 for i in range(reps):
     t = time.time(); img, s = H.gpu_render(g, w, h); dt = time.time() - t

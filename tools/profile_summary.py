@@ -19,7 +19,7 @@ traffic = {"workload": bench["config"]["workload"], "rays_per_step": rays_per_st
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel(?:<\w+>)?)", name)
+    m = re.search(r"(\w+_kernel(?:<[\w, ]+>)?)", name)
     return m.group(1) if m else name[:40]
 
 
@@ -41,7 +41,7 @@ for tag, scale in (("fetch", 1.0), ("write", 1.0)):
     for (k, c), v in sorted(acc.items()):
         print(f"{k:32s} {c:12s} dispatches {cnt[(k, c)]:7d} total_GB {v*1024*scale/1e9:10.3f} "
               f"per_launch_MB {v*1024*scale/cnt[(k, c)]/1e6:10.3f}")
-        if k.endswith("_kernel<false>") or k in ("shade_pbr_kernel", "generate_kernel"):
+        if "_kernel<false" in k or k == "generate_kernel":
             # the counter passes render ONE step, so bytes / rays_per_step is the HBM-side traffic per ray
             traffic["kernels"].setdefault(k, {})[tag + "_bytes_per_ray"] = v * 1024 * scale / rays_per_step
 open(root + "/hbm_traffic.json", "w").write(json.dumps(traffic, indent=1) + "\n")
