@@ -81,6 +81,22 @@ __device__ __forceinline__ float dop_forward_distance(const float* __restrict__ 
     return forward_distance(hit, tmin, tmax);
 }
 
+// The same test for rays whose seven inverse projections are all finite: no operand can be NaN then, so hardware
+// min / max give what the compare-and-select forms above give, and "some slab interval is empty" can be decided once
+// at the end (tmin only grows, tmax only shrinks).
+__device__ __forceinline__ float dop_forward_distance_finite(const float* __restrict__ dop, const DopRay& pr) {
+    float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float t0 = (dop[2 * i] - pr.op[i]) * pr.ip[i];
+        const float t1 = (dop[2 * i + 1] - pr.op[i]) * pr.ip[i];
+        tmin = __builtin_fmaxf(tmin, __builtin_fminf(t0, t1));
+        tmax = __builtin_fminf(tmax, __builtin_fmaxf(t0, t1));
+        if (i == 2 && __ballot(tmin <= tmax) == 0ull) return kInfF;
+    }
+    return forward_distance(tmin <= tmax, tmin, tmax);
+}
+
 struct LaneHit {
     float t, A, B;
     uint32_t tri, object;
@@ -398,8 +414,12 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
 #pragma unroll
     for (int j = 0; j < kCandMax; ++j) { key[j] = kInfF; slot[j] = PT_NO_NODE; }
     const uint32_t n_inst = sc.n_instances;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) finite = finite && (fabsf(pr.ip[i]) < kInfF);
+    const bool wave_finite = __ballot(!finite) == 0ull;  // (lanes past the end of the queue have left already)
     for (uint32_t k = 0; k < n_inst; ++k) {
-        const float dist = dop_forward_distance(sc.instances[k].dop, pr);
+        const float dist = wave_finite ? dop_forward_distance_finite(sc.instances[k].dop, pr) : dop_forward_distance(sc.instances[k].dop, pr);
         if (__ballot(dist < kInfF) == 0ull) continue;  // no ray of this wavefront touches the instance: skip the insertion
         if (dist < kInfF) {
             // sorted insertion; strict '<' keeps table order among equal distances
