@@ -350,6 +350,9 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_BURST
 #define PT_BURST 8
 #endif
+#ifndef PT_SERVICE_MIN_WIDE
+#define PT_SERVICE_MIN_WIDE 32  // measured: 16 / 24 / 32 / 40 / 48 -> extend 26.7 / 26.2 / 25.7 / 26.2 / 27.5 ms (README stand-in, 16 spp)
+#endif
 #ifndef PT_WIDE_SORT
 #define PT_WIDE_SORT 2
 #endif
@@ -555,7 +558,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             }
         };
         const uint32_t n_wait = n_next + (claim.exhausted ? 0u : n_idle);  // lanes that a service pass can move on
-        if (n_wait && (n_wait >= PT_SERVICE_MIN || (n_inner + n_leaf) == 0u)) {
+        if (n_wait && (n_wait >= (WIDE ? PT_SERVICE_MIN_WIDE : PT_SERVICE_MIN) || (n_inner + n_leaf) == 0u)) {
             // ================= service: finish instances, hand out rays, enter instances =================
             // One pass serves every lane that is not traversing, so a lane waits once between two instances
             // instead of once per kind of service:
