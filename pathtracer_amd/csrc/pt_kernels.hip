@@ -774,7 +774,45 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             // ================= triangle tests for the lanes that hold a leaf =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
-                if (is_leaf(cur)) {
+                if (WIDE && is_leaf(cur)) {
+                    // Two triangles a step: the trees of this layout have leaves of at most two, and fetching both at once
+                    // takes one of the two dependent round trips out of a leaf visit.  (The record after the last
+                    // triangle of the array is padding.)  Tested in leaf order, so the first found still wins a tie.
+                    if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
+                    const float4* tp = reinterpret_cast<const float4*>(sc.tris + (cur & ~PT_LEAF_BIT));
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2], r0 = tp[3], r1 = tp[4], r2 = tp[5];
+                    const uint32_t top = peek();
+                    float A, B, t;
+                    bool bf;
+                    const bool ok = ray_triangle(o, d, f3{q0.x, q0.y, q0.z}, f3{q0.w, q1.x, q1.y}, f3{q1.z, q1.w, q2.x},
+                                                 (flags & F_CULL) != 0, A, B, t, bf);
+                    bool stop = false;
+                    if (ok && !(t < 0.0f) && !(t >= h_t)) {
+                        h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                        h_tri = __float_as_uint(q2.y);
+                        stop = (flags & F_ANY) != 0;
+                    }
+                    uint32_t left_after = __float_as_uint(q2.z) - 1u;  // triangles of the leaf after the first
+                    if (!stop && left_after != 0u) {
+                        if (COUNT) ++cnt.tris;
+                        const bool ok2 = ray_triangle(o, d, f3{r0.x, r0.y, r0.z}, f3{r0.w, r1.x, r1.y}, f3{r1.z, r1.w, r2.x},
+                                                      (flags & F_CULL) != 0, A, B, t, bf);
+                        if (ok2 && !(t < 0.0f) && !(t >= h_t)) {
+                            h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                            h_tri = __float_as_uint(r2.y);
+                            stop = (flags & F_ANY) != 0;
+                        }
+                        left_after -= 1u;
+                    }
+                    if (stop) {
+                        cur = PT_NO_NODE;
+                    } else if (left_after != 0u) {
+                        cur = cur + 2u;
+                    } else {
+                        pop_to(top);
+                    }
+                }
+                if (!WIDE && is_leaf(cur)) {
                     if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
                     const float4* tp = reinterpret_cast<const float4*>(sc.tris + (cur & ~PT_LEAF_BIT));
                     const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];

@@ -973,7 +973,9 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         q.right = n.right;
         q.pad0 = q.pad1 = 0;
     }
-    std::vector<ptd::TriQ> q_tris(all_tris.size());
+    std::vector<ptd::TriQ> q_tris(all_tris.size() + 1);  // + one record of padding: the four-wide kernel reads triangles in pairs
+    std::memset(&q_tris.back(), 0, sizeof(ptd::TriQ));
+    q_tris.back().leaf_count = 1;
     uint32_t in_leaf = 0;  // the builder marks a leaf's first triangle with the leaf size; every triangle gets the rest count
     for (size_t i = 0; i < all_tris.size(); ++i) {
         const ptd::DevTri& t = all_tris[i];
