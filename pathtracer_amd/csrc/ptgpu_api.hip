@@ -325,7 +325,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     }
     // Spawned generations outgrow the camera batch (up to ~3x for the branching PBR estimator); launching a whole
     // generation at once saves the tail of every extra launch, so launches may be four batches long.
-    const uint64_t L_want = fanout > 1 ? std::min<uint64_t>(4 * K, 1ull << 28) : K;
+    const uint64_t L_want = fanout > 1 ? std::min<uint64_t>(4 * K, 1ull << 28) : (fanout == 1 ? 2 * K : K);
     int rc = ensure_work_memory(c, fanout, bounces, K, L_want);
     if (rc) return rc;
     const uint64_t L = c->launch_cap;
@@ -359,10 +359,11 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     std::vector<Frame> frames;
     float ms = 0.0f;
     const bool verbose_launches = std::getenv("PTGPU_VERBOSE") && std::atoi(std::getenv("PTGPU_VERBOSE")) >= 2;
-    // A generation that has shrunk to a sliver (the alpha pass-through chains at the end of a batch: a handful of
-    // launches of a few thousand rays each) is not worth launches of its own while another batch follows: it stays in
-    // its pool and the next batch's camera rays go on top of it.  Rays carry their own depth, so generations may mix.
-    const uint64_t carry_below = K / 32;
+    // Rays carry their own depth, so generations may mix: when what a generation spawned still fits a launch together
+    // with the next batch's camera rays, it is not launched on its own — the camera rays go on top of it in its pool.
+    // Launches stay full that way (a generation shrinks from bounce to bounce; the alpha pass-through chains at the
+    // end of a batch are slivers of a few thousand rays), and every launch saved is a tail saved.
+    const uint64_t carry_below = (L > K) ? L - K + 1 : K / 32;
     int gen_pool = 0;  // pool that receives the next batch's camera rays (the one holding carried rays, if any)
     c->pools[0].top = c->pools[1].top = 0;
     for (uint64_t first = 0; first < total; first += K) {
