@@ -677,14 +677,14 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     // estimated the way the surface area heuristic does: a node is visited in proportion to the area of its box,
     // summed over the instances of its mesh (scaled by the instance's size).  Only the numbering changes.
     uint32_t n_top = 0;
+    std::vector<float> mesh_weight(model->n_meshes, 0.0f);  // summed squared scale of a mesh's instances
+    for (const ptd::DevXform& xf : table.xforms) {
+        const float* m = xf.model;  // columns c0 c1 c2 (c3 = translation)
+        const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[3] * (m[1] * m[8] - m[2] * m[7]) + m[6] * (m[1] * m[5] - m[2] * m[4]);
+        const float scale = std::cbrt(std::fabs(det));
+        mesh_weight[xf.mesh_index] += scale * scale;
+    }
     if (!all_nodes.empty()) {
-        std::vector<float> mesh_weight(model->n_meshes, 0.0f);
-        for (const ptd::DevXform& xf : table.xforms) {
-            const float* m = xf.model;  // columns c0 c1 c2 (c3 = translation)
-            const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[3] * (m[1] * m[8] - m[2] * m[7]) + m[6] * (m[1] * m[5] - m[2] * m[4]);
-            const float scale = std::cbrt(std::fabs(det));
-            mesh_weight[xf.mesh_index] += scale * scale;
-        }
         auto half_area = [](const float* lo, const float* hi) {
             const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
             return dx * dy + dx * dz + dy * dz;
@@ -743,7 +743,6 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
             std::memcpy(out[0].lo, nd.l_lo, 12); std::memcpy(out[0].hi, nd.l_hi, 12);
             std::memcpy(out[1].lo, nd.r_lo, 12); std::memcpy(out[1].hi, nd.r_hi, 12);
         };
-        std::vector<uint32_t> wide_of(all_nodes.size(), PT_NO_NODE);  // binary node -> wide node made from it
         std::vector<uint32_t> depth_of;                               // per wide node
         uint32_t max_depth4 = 0;
         struct Todo {
@@ -755,7 +754,6 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
             wide.emplace_back();
             depth_of.push_back(depth);
             max_depth4 = std::max(max_depth4, depth);
-            wide_of[binary] = w;
             todo.push_back({binary, w});
             return w;
         };
@@ -826,13 +824,6 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         for (ptd::DevXform& xf : table.xforms) xf.root4 = mesh_root4[xf.mesh_index];
         // the most visited wide nodes first (same estimate as for the binary nodes), kept in LDS by the kernel
         {
-            std::vector<float> mesh_weight(model->n_meshes, 0.0f);
-            for (const ptd::DevXform& xf : table.xforms) {
-                const float* m = xf.model;
-                const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[3] * (m[1] * m[8] - m[2] * m[7]) + m[6] * (m[1] * m[5] - m[2] * m[4]);
-                const float scale = std::cbrt(std::fabs(det));
-                mesh_weight[xf.mesh_index] += scale * scale;
-            }
             struct Entry {
                 float priority;
                 uint32_t node, mesh;

@@ -461,6 +461,17 @@ def test_full_size_stress_geometry_properties():
     d = np.abs(img[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
     assert (d <= 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).all(), d.max()
     assert (hits["hit"] != 0).mean() > 0.2
+    # the same frame over four-wide nodes, on the host-built and on the device-built tree: the same primary hits (ties
+    # in distance excepted), the same band
+    for as_type in (1, 2):
+        gw = H.make_gpu(model, None, H.settings(program=2, spp=1, bounces=8, as_type=as_type, wide=True), w, h)
+        exact, _ = H.hits_equal(hits, gw.render_hits(w, h))
+        assert exact.mean() >= 0.9999, f"as_type {as_type}: {(~exact).sum()} of {w * h} primary-hit records differ"
+        img_w, sw = H.gpu_render(gw, w, h)
+        assert abs(int(sw.rays) - int(s.rays)) <= 1e-4 * s.rays
+        dw = np.abs(img_w[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
+        assert (dw > 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).any(axis=-1).mean() <= 1e-3
+        del gw
 
 
 def test_full_size_material_stress_properties():
