@@ -1,5 +1,5 @@
-// app_capi.cc — two plain-C entry points of libptapp.so for callers without a C++ toolchain (the Python tests):
-// scene conversion through ModelLoader and image decoding.  Neither touches the GPU.
+// app_capi.cc — plain-C entry points of libptapp.so for callers without a C++ toolchain (the Python tests):
+// scene conversion through ModelLoader, image decoding, tangent generation.  None touches the GPU.
 #include <cstdio>
 #include <cstring>
 #include <exception>
@@ -38,6 +38,30 @@ int ptapp_decode_image(const unsigned char* bytes, size_t n, int* width, int* he
         if (rgba && capacity >= d.rgba.size()) std::memcpy(rgba, d.rgba.data(), d.rgba.size());
     } catch (const std::exception& e) {
         if (err && err_len) std::snprintf(err, err_len, "%s", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// MikkTSpace tangents (app::compute_tangents_mikk) of an indexed triangle mesh given as plain arrays: positions and
+// normals 3 floats, uvs 2 floats per vertex; writes 4 floats per vertex (xyz, sign).  0 on success.
+int ptapp_compute_tangents(const float* positions, const float* normals, const float* uvs, size_t n_vertices, const unsigned* indices,
+                           size_t n_indices, float* tangents_out) {
+    if (!positions || !normals || !uvs || !indices || !tangents_out || n_indices % 3 != 0) return -1;
+    try {
+        app::Mesh mesh;
+        mesh.vertices.resize(n_vertices);
+        for (size_t i = 0; i < n_vertices; ++i) {
+            mesh.vertices[i].position = app::fvec3{positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]};
+            mesh.vertices[i].normal = app::fvec3{normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]};
+            mesh.vertices[i].uv = app::fvec2{uvs[2 * i], uvs[2 * i + 1]};
+        }
+        for (size_t k = 0; k < n_indices; ++k)
+            if (indices[k] >= n_vertices) return -1;
+        mesh.indices.assign(indices, indices + n_indices);
+        app::compute_tangents_mikk(mesh);
+        for (size_t i = 0; i < n_vertices; ++i) std::memcpy(tangents_out + 4 * i, &mesh.vertices[i].tangent.x, 16);
+    } catch (const std::exception&) {
         return -1;
     }
     return 0;

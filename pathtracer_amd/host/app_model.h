@@ -163,6 +163,10 @@ class ModelLoader {
     Model model_;
 };
 
+// Tangents of a mesh with uv but without TANGENT: the MikkTSpace algorithm as the reference runs it
+// (src/compute_tangents.cc:9-62), written into the indexed vertices (mikk_tangents.cc).
+void compute_tangents_mikk(Mesh& mesh);
+
 // Writes the flat scene container ("PTSC0001"); the inverse of ModelLoader for that format.
 bool save_scene_container(const Model& model, const std::filesystem::path& path);
 

@@ -10,9 +10,8 @@
 //   * one Mesh per primitive; TEXCOORD_0 only, uv = 0 when absent; tangents from TANGENT, else generated (:134-194);
 //   * the default scene's node tree flattened: one Object per primitive of a node's mesh with
 //     NormalMatrix = transpose(inverse(Model)); cameras with their node matrix (:195-210).
-// Not reproduced: MikkTSpace.  Meshes with uv but no TANGENT get per-vertex tangents accumulated from the triangles'
-// uv gradients and orthogonalised against the normal — the same tangent space on smooth, consistently mapped meshes,
-// not the vertex-splitting of MikkTSpace at uv seams.  The no-uv fallback is the reference's (compute_tangents.cc:64-70).
+// Meshes with uv but no TANGENT get MikkTSpace tangents (mikk_tangents.cc, a restatement of the published algorithm —
+// the library is not in the reference's tree); the no-uv fallback is the reference's (compute_tangents.cc:64-70).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -341,40 +340,6 @@ void compute_tangents_no_uv(Mesh& mesh) {  // compute_tangents.cc:64-70
         v.tangent = fvec4{t.x, t.y, t.z, 1.0f};
     }
 }
-void compute_tangents_from_uv(Mesh& mesh) {
-    std::vector<fvec3> tan(mesh.vertices.size()), bit(mesh.vertices.size());
-    for (size_t i = 0; i + 2 < mesh.indices.size(); i += 3) {
-        const uint32_t ia = mesh.indices[i], ib = mesh.indices[i + 1], ic = mesh.indices[i + 2];
-        const vertex &a = mesh.vertices[ia], &b = mesh.vertices[ib], &c = mesh.vertices[ic];
-        const fvec3 e1 = sub3(b.position, a.position), e2 = sub3(c.position, a.position);
-        const float du1 = b.uv.x - a.uv.x, dv1 = b.uv.y - a.uv.y, du2 = c.uv.x - a.uv.x, dv2 = c.uv.y - a.uv.y;
-        const float det = du1 * dv2 - du2 * dv1;
-        if (det == 0.0f) continue;
-        const float r = 1.0f / det;
-        const fvec3 t{(e1.x * dv2 - e2.x * dv1) * r, (e1.y * dv2 - e2.y * dv1) * r, (e1.z * dv2 - e2.z * dv1) * r};
-        const fvec3 s{(e2.x * du1 - e1.x * du2) * r, (e2.y * du1 - e1.y * du2) * r, (e2.z * du1 - e1.z * du2) * r};
-        for (uint32_t k : {ia, ib, ic}) {
-            tan[k] = {tan[k].x + t.x, tan[k].y + t.y, tan[k].z + t.z};
-            bit[k] = {bit[k].x + s.x, bit[k].y + s.y, bit[k].z + s.z};
-        }
-    }
-    for (size_t k = 0; k < mesh.vertices.size(); ++k) {
-        vertex& v = mesh.vertices[k];
-        const float nt = dot3(v.normal, tan[k]);
-        fvec3 t{tan[k].x - v.normal.x * nt, tan[k].y - v.normal.y * nt, tan[k].z - v.normal.z * nt};
-        const float len = std::sqrt(dot3(t, t));
-        if (!(len > 1e-20f)) {  // no usable uv gradient at this vertex: any direction perpendicular to the normal
-            const fvec3 up = std::fabs(v.normal.y) < 0.99f ? fvec3{0.0f, 1.0f, 0.0f} : fvec3{1.0f, 0.0f, 0.0f};
-            t = cross3(v.normal, up);
-            const float l2 = std::sqrt(dot3(t, t));
-            v.tangent = fvec4{t.x / l2, t.y / l2, t.z / l2, 1.0f};
-            continue;
-        }
-        const float sign = dot3(cross3(v.normal, t), bit[k]) < 0.0f ? -1.0f : 1.0f;
-        v.tangent = fvec4{t.x / len, t.y / len, t.z / len, sign};
-    }
-}
-
 int texture_image(const Asset& a, const Json* tex_info) {  // model_loader.cc:74-94
     if (!tex_info) return -1;
     const long t = tex_info->index("index");
@@ -554,7 +519,7 @@ Model load_gltf_model(const std::filesystem::path& path) {
                 const Asset::Accessor tg = asset.accessor(attrs->index("TANGENT"), "tangents");
                 for (size_t i = 0; i < std::min(tg.count, pos.count); ++i) element_as_floats(tg, i, &mesh.vertices[i].tangent.x, 4);
             } else if (has_uv) {
-                compute_tangents_from_uv(mesh);
+                compute_tangents_mikk(mesh);  // compute_tangents.cc:58-62
             } else {
                 compute_tangents_no_uv(mesh);
             }

@@ -183,3 +183,84 @@ def test_gltf_errors(lib, tmp_path):
     bad.write_bytes(b"glTF" + struct.pack("<II", 2, 1000) + b"\0" * 20)
     with pytest.raises(RuntimeError, match="loadFromFile failed"):
         convert(lib, bad, tmp_path / "x.ptsc")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tangents for meshes with uv but without TANGENT (the MikkTSpace algorithm, src/compute_tangents.cc:9-62).
+# Parity unpinned: the library is absent from the reference and its tests hold no tangent vectors; these are
+# analytic cases and invariances of the published algorithm.
+# ---------------------------------------------------------------------------------------------------------------
+def tangents(lib, pos, nrm, uv, idx):
+    pos = np.ascontiguousarray(pos, np.float32)
+    nrm = np.ascontiguousarray(nrm, np.float32)
+    uv = np.ascontiguousarray(uv, np.float32)
+    idx = np.ascontiguousarray(idx, np.uint32).reshape(-1)
+    out = np.zeros((len(pos), 4), np.float32)
+    fp = C.POINTER(C.c_float)
+    lib.ptapp_compute_tangents.restype = C.c_int
+    lib.ptapp_compute_tangents.argtypes = [fp, fp, fp, C.c_size_t, C.POINTER(C.c_uint), C.c_size_t, fp]
+    rc = lib.ptapp_compute_tangents(pos.ctypes.data_as(fp), nrm.ctypes.data_as(fp), uv.ctypes.data_as(fp), len(pos),
+                                    idx.ctypes.data_as(C.POINTER(C.c_uint)), len(idx), out.ctypes.data_as(fp))
+    assert rc == 0
+    return out
+
+
+def _grid(n, mirror=False):
+    """(n+1)^2 vertices in the xz plane, normal +y, uv = (x, z) (or (-x, z)), triangles wound to face +y."""
+    xs, zs = np.meshgrid(np.linspace(0, 1, n + 1), np.linspace(0, 1, n + 1), indexing="ij")
+    pos = np.stack([xs.ravel(), np.zeros(xs.size), zs.ravel()], axis=1)
+    nrm = np.tile([0.0, 1.0, 0.0], (len(pos), 1))
+    uv = np.stack([-xs.ravel() if mirror else xs.ravel(), zs.ravel()], axis=1)
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            a, b, c, d = i * (n + 1) + j, i * (n + 1) + j + 1, (i + 1) * (n + 1) + j, (i + 1) * (n + 1) + j + 1
+            tris += [(a, b, c), (b, d, c)]  # (0,0,1) x (1,0,0) = +y
+    return pos, nrm, uv, np.array(tris)
+
+
+def test_tangents_of_a_plane_follow_u(lib):
+    pos, nrm, uv, tris = _grid(4)
+    t = tangents(lib, pos, nrm, uv, tris)
+    assert np.allclose(t[:, :3], [1.0, 0.0, 0.0], atol=1e-6)
+    # bitangent = cross(n, t) * w must point along +z, where v grows: cross(+y, +x) = -z, so w = -1
+    assert (t[:, 3] == -1.0).all()
+    pos, nrm, uv, tris = _grid(4, mirror=True)
+    t = tangents(lib, pos, nrm, uv, tris)
+    assert np.allclose(t[:, :3], [-1.0, 0.0, 0.0], atol=1e-6) and (t[:, 3] == 1.0).all()
+
+
+def test_tangents_of_a_sphere_and_welding(lib):
+    pos, nrm, tris, uv, analytic = scenes.uv_sphere(24, 48)
+    t = tangents(lib, pos, nrm, uv, tris)
+    assert np.isfinite(t).all()
+    ring = (np.abs(pos[:, 1]) < 0.9 * np.abs(pos).max())  # away from the poles
+    assert np.allclose(np.linalg.norm(t[ring, :3], axis=1), 1.0, atol=1e-5)
+    assert np.abs((t[ring, :3] * nrm[ring]).sum(axis=1)).max() < 1e-5          # in the tangent plane
+    # the direction in which u grows at constant v: around the y axis
+    around = np.cross(np.tile([0.0, 1.0, 0.0], (len(pos), 1)), nrm)
+    around /= np.maximum(np.linalg.norm(around, axis=1, keepdims=True), 1e-12)
+    align = np.abs((t[ring, :3] * around[ring]).sum(axis=1))
+    assert align.min() > 0.99
+    assert len(np.unique(t[ring, 3])) == 1                                     # one orientation all over
+    assert ((t[ring, :3] * analytic[ring, :3]).sum(axis=1) > 0.99).all()
+    # the sign is the library's: +1 where the uv mapping keeps the orientation of the triangles' winding (here: outward
+    # winding, positive uv area), whatever sign the scene generator chose for the tangents it ships itself
+    assert (t[ring, 3] == 1.0).all()
+    # the same surface as a triangle soup (every corner its own vertex): welding must give every copy the same tangent
+    soup_idx = tris.reshape(-1)
+    ts = tangents(lib, pos[soup_idx], nrm[soup_idx], uv[soup_idx], np.arange(len(soup_idx)))
+    seam = np.isin(soup_idx, np.nonzero((uv[:, 0] == uv[:, 0].min()) | (uv[:, 0] == uv[:, 0].max()))[0])
+    keep = ring[soup_idx] & ~seam
+    assert np.allclose(ts[keep], t[soup_idx][keep], atol=1e-5)
+
+
+def test_tangents_survive_degenerate_and_unmapped_triangles(lib):
+    pos, nrm, uv, tris = _grid(3)
+    base = tangents(lib, pos, nrm, uv, tris)
+    extra = np.array([(0, 0, 5), (1, 1, 1)])                  # two corners at one position; all three at one
+    t = tangents(lib, pos, nrm, uv, np.concatenate([tris, extra]))
+    assert np.isfinite(t).all() and np.array_equal(t, base)
+    uv0 = np.zeros_like(uv)                                   # no uv area anywhere: the library's default tangent space
+    t0 = tangents(lib, pos, nrm, uv0, tris)
+    assert np.isfinite(t0).all() and np.allclose(t0[:, :3], [1.0, 0.0, 0.0]) and (t0[:, 3] == -1.0).all()
