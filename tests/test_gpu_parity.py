@@ -359,10 +359,22 @@ def test_error_behaviour(tiny):
         r.load_scene(bad, env)
     with pytest.raises(RuntimeError):
         r.set_render_settings(RenderSettings(1, 1, 0, 8, 0.0, 7, 1))  # program mode out of range
+    with pytest.raises(RuntimeError):
+        r.set_render_settings(RenderSettings(1, 1, 0, 8, 0.0, 2, 3))  # acceleration structure type out of range
+    import ctypes
+    raw = H.settings(program=2, spp=2).to_abi()
+    raw.flags = 8  # unknown flag bit
+    assert r._L.ptgpu_set_render_settings(r._h, ctypes.byref(raw)) < 0 and b"flag" in r._L.ptgpu_last_error(r._h)
     r.set_render_settings(H.settings(program=2, spp=2))
     r.load_scene(model, env)
     with pytest.raises(RuntimeError):  # camera state never set
         r.render_frame(CPUFrameBuffer(8, 8))
+    # the brute-force structure ignores the wide-node flag (one leaf per mesh: nothing to widen) and still matches
+    w, h = 32, 18
+    g = H.make_gpu(model, env, H.settings(program=0, as_type=0, wide=True), w, h)
+    o = H.make_oracle(model, env, H.settings(program=0, as_type=0), w, h)
+    exact, _ = H.hits_equal(o.render_hits(w, h), g.render_hits(w, h))
+    assert exact.all()
 
 
 def test_full_size_readme_frame_properties():
