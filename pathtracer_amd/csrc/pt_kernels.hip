@@ -539,6 +539,82 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
         sp = (sp > 0) ? sp - 1 : 0;
     };
 
+    // One step over a four-wide node (its four quarters q0 q1 q2 rr already loaded): enter the nearest child whose box is
+    // entered before the current hit, push the others far to near, or pop.
+    auto wide_node_step = [&](float4 q0, float4 q1, float4 q2, float4 rr, uint32_t top) {
+            // planes: origin + scale * q.  With the ray folded in, a plane's distance is A + q * B per axis.
+            const uint32_t lqx = __float_as_uint(q1.z), lqy = __float_as_uint(q1.w), lqz = __float_as_uint(q2.x);
+            const uint32_t hqx = __float_as_uint(q2.y), hqy = __float_as_uint(q2.z), hqz = __float_as_uint(q2.w);
+            float d0, d1, d2, d3;
+            if (!(flags & F_SLOW)) {
+                const float ax = (q0.x - o.x) * inv.x, ay = (q0.y - o.y) * inv.y, az = (q0.z - o.z) * inv.z;
+                const float bx = q0.w * inv.x, by = q1.x * inv.y, bz = q1.y * inv.z;
+                auto entry = [&](int k) {
+                    const int sh = 8 * k;
+                    const float lx = __builtin_fmaf(static_cast<float>((lqx >> sh) & 0xffu), bx, ax);
+                    const float hx = __builtin_fmaf(static_cast<float>((hqx >> sh) & 0xffu), bx, ax);
+                    const float ly = __builtin_fmaf(static_cast<float>((lqy >> sh) & 0xffu), by, ay);
+                    const float hy = __builtin_fmaf(static_cast<float>((hqy >> sh) & 0xffu), by, ay);
+                    const float lz = __builtin_fmaf(static_cast<float>((lqz >> sh) & 0xffu), bz, az);
+                    const float hz = __builtin_fmaf(static_cast<float>((hqz >> sh) & 0xffu), bz, az);
+                    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fminf(lz, hz));
+                    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz));
+                    return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
+                };
+                d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
+            } else {  // an infinite inverse direction: planes decoded, exact select forms
+                auto entry = [&](int k) {
+                    const int sh = 8 * k;
+                    bool hh;
+                    float dd;
+                    box_test(q0.x + q0.w * static_cast<float>((lqx >> sh) & 0xffu), q0.y + q1.x * static_cast<float>((lqy >> sh) & 0xffu),
+                             q0.z + q1.y * static_cast<float>((lqz >> sh) & 0xffu), q0.x + q0.w * static_cast<float>((hqx >> sh) & 0xffu),
+                             q0.y + q1.x * static_cast<float>((hqy >> sh) & 0xffu), q0.z + q1.y * static_cast<float>((hqz >> sh) & 0xffu),
+                             o, inv, hh, dd);
+                    return dd;
+                };
+                d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
+            }
+            uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
+            // a child is a candidate when it exists and its box is entered nearer than the current hit
+            d0 = (r0 != PT_NO_NODE && h_t > d0) ? d0 : kInfF;
+            d1 = (r1 != PT_NO_NODE && h_t > d1) ? d1 : kInfF;
+            d2 = (r2 != PT_NO_NODE && h_t > d2) ? d2 : kInfF;
+            d3 = (r3 != PT_NO_NODE && h_t > d3) ? d3 : kInfF;
+            auto order = [](float& da, uint32_t& ra, float& db, uint32_t& rb) {
+                const bool swap = db < da;
+                const float dn = swap ? db : da, df = swap ? da : db;
+                const uint32_t rn = swap ? rb : ra, rf = swap ? ra : rb;
+                da = dn; db = df; ra = rn; rb = rf;
+            };
+#if PT_WIDE_SORT == 2
+            order(d0, r0, d1, r1);
+            order(d2, r2, d3, r3);
+            order(d0, r0, d2, r2);
+            order(d1, r1, d3, r3);
+            order(d1, r1, d2, r2);
+#else  // the nearest child to the front, the others in slot order
+            order(d0, r0, d1, r1);
+            order(d2, r2, d3, r3);
+            order(d0, r0, d2, r2);
+#endif
+            auto push = [&](uint32_t ref) {
+                if (sp < kStackLds) s_stack[sp][tid] = ref;
+                else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
+                    spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = ref;
+                ++sp;
+            };
+            if (d0 < kInfF) {  // nearest first; the others wait on the stack, the nearer the higher
+                if (d3 < kInfF) push(r3);
+                if (d2 < kInfF) push(r2);
+                if (d1 < kInfF) push(r1);
+                cur = r0;
+            } else {
+                pop_to(top);
+            }
+        
+    };
+
     for (;;) {
         // ---- census of lane states (wave-uniform scalars) ----
         const unsigned long long m_idle = __ballot(cur == PT_IDLE);
@@ -656,76 +732,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     }
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], rr = np[3];
                     const uint32_t top = peek();
-                    // planes: origin + scale * q.  With the ray folded in, a plane's distance is A + q * B per axis.
-                    const uint32_t lqx = __float_as_uint(q1.z), lqy = __float_as_uint(q1.w), lqz = __float_as_uint(q2.x);
-                    const uint32_t hqx = __float_as_uint(q2.y), hqy = __float_as_uint(q2.z), hqz = __float_as_uint(q2.w);
-                    float d0, d1, d2, d3;
-                    if (!(flags & F_SLOW)) {
-                        const float ax = (q0.x - o.x) * inv.x, ay = (q0.y - o.y) * inv.y, az = (q0.z - o.z) * inv.z;
-                        const float bx = q0.w * inv.x, by = q1.x * inv.y, bz = q1.y * inv.z;
-                        auto entry = [&](int k) {
-                            const int sh = 8 * k;
-                            const float lx = __builtin_fmaf(static_cast<float>((lqx >> sh) & 0xffu), bx, ax);
-                            const float hx = __builtin_fmaf(static_cast<float>((hqx >> sh) & 0xffu), bx, ax);
-                            const float ly = __builtin_fmaf(static_cast<float>((lqy >> sh) & 0xffu), by, ay);
-                            const float hy = __builtin_fmaf(static_cast<float>((hqy >> sh) & 0xffu), by, ay);
-                            const float lz = __builtin_fmaf(static_cast<float>((lqz >> sh) & 0xffu), bz, az);
-                            const float hz = __builtin_fmaf(static_cast<float>((hqz >> sh) & 0xffu), bz, az);
-                            const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx, hx), __builtin_fminf(ly, hy)), __builtin_fminf(lz, hz));
-                            const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx, hx), __builtin_fmaxf(ly, hy)), __builtin_fmaxf(lz, hz));
-                            return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
-                        };
-                        d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
-                    } else {  // an infinite inverse direction: planes decoded, exact select forms
-                        auto entry = [&](int k) {
-                            const int sh = 8 * k;
-                            bool hh;
-                            float dd;
-                            box_test(q0.x + q0.w * static_cast<float>((lqx >> sh) & 0xffu), q0.y + q1.x * static_cast<float>((lqy >> sh) & 0xffu),
-                                     q0.z + q1.y * static_cast<float>((lqz >> sh) & 0xffu), q0.x + q0.w * static_cast<float>((hqx >> sh) & 0xffu),
-                                     q0.y + q1.x * static_cast<float>((hqy >> sh) & 0xffu), q0.z + q1.y * static_cast<float>((hqz >> sh) & 0xffu),
-                                     o, inv, hh, dd);
-                            return dd;
-                        };
-                        d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
-                    }
-                    uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
-                    // a child is a candidate when it exists and its box is entered nearer than the current hit
-                    d0 = (r0 != PT_NO_NODE && h_t > d0) ? d0 : kInfF;
-                    d1 = (r1 != PT_NO_NODE && h_t > d1) ? d1 : kInfF;
-                    d2 = (r2 != PT_NO_NODE && h_t > d2) ? d2 : kInfF;
-                    d3 = (r3 != PT_NO_NODE && h_t > d3) ? d3 : kInfF;
-                    auto order = [](float& da, uint32_t& ra, float& db, uint32_t& rb) {
-                        const bool swap = db < da;
-                        const float dn = swap ? db : da, df = swap ? da : db;
-                        const uint32_t rn = swap ? rb : ra, rf = swap ? ra : rb;
-                        da = dn; db = df; ra = rn; rb = rf;
-                    };
-#if PT_WIDE_SORT == 2
-                    order(d0, r0, d1, r1);
-                    order(d2, r2, d3, r3);
-                    order(d0, r0, d2, r2);
-                    order(d1, r1, d3, r3);
-                    order(d1, r1, d2, r2);
-#else  // the nearest child to the front, the others in slot order
-                    order(d0, r0, d1, r1);
-                    order(d2, r2, d3, r3);
-                    order(d0, r0, d2, r2);
-#endif
-                    auto push = [&](uint32_t ref) {
-                        if (sp < kStackLds) s_stack[sp][tid] = ref;
-                        else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
-                            spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = ref;
-                        ++sp;
-                    };
-                    if (d0 < kInfF) {  // nearest first; the others wait on the stack, the nearer the higher
-                        if (d3 < kInfF) push(r3);
-                        if (d2 < kInfF) push(r2);
-                        if (d1 < kInfF) push(r1);
-                        cur = r0;
-                    } else {
-                        pop_to(top);
-                    }
+                    wide_node_step(q0, q1, q2, rr, top);
                 }
                 if (!WIDE && is_node(cur)) {
                     if (COUNT) { ++cnt.nodes; if (first_active_lane()) ++cnt.wave_inner; }
