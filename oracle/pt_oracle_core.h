@@ -655,8 +655,11 @@ struct MeshBvh {
             float c = (t.p1[best_axis] + t.p2[best_axis] + t.p3[best_axis]) / 3.0f;
             return c < best_center;
         });
-        if (best != parent) return begin + static_cast<uint32_t>(mid - tb);
-        if (static_cast<uint32_t>(n) <= max_leaf) return end;
+        // An empty left part (every centroid right of the bins' plane once compared in binary32) makes the reference
+        // recurse without end (:443-444); the median split is taken instead — the one deviation from its tree.
+        const bool empty_left = (best != parent) && mid == tb;
+        if (best != parent && !empty_left) return begin + static_cast<uint32_t>(mid - tb);
+        if (!empty_left && static_cast<uint32_t>(n) <= max_leaf) return end;
         if (mid == tb || mid == te || mid == tb + 1 || mid + 1 == te) {
             std::sort(tb, te, [best_axis](const BvhTri& a, const BvhTri& b) {
                 return (a.p1[best_axis] + a.p2[best_axis] + a.p3[best_axis]) <

@@ -134,8 +134,12 @@ uint32_t choose_split(std::vector<ptd::DevTri>& tris, uint32_t begin, uint32_t e
     ptd::DevTri* mid = std::partition(first, last, [plane, best_axis](const ptd::DevTri& t) {
         return centroid3(t, best_axis) / 3.0f < plane;
     });
-    if (improved) return begin + static_cast<uint32_t>(mid - first);
-    if (static_cast<uint32_t>(n) <= max_leaf) return end;
+    // A split plane found by the bins can leave every centroid on its right once compared in binary32 (meshes far from
+    // their origin): an empty left part, and a right part equal to the parent.  The reference recurses without end
+    // there (:443-444); this builder takes the median split in that case — its only deviation from the reference's tree.
+    const bool empty_left = improved && mid == first;
+    if (improved && !empty_left) return begin + static_cast<uint32_t>(mid - first);
+    if (!empty_left && static_cast<uint32_t>(n) <= max_leaf) return end;
     if (mid == first || mid == last || mid == first + 1 || mid + 1 == last) {
         std::sort(first, last, [best_axis](const ptd::DevTri& a, const ptd::DevTri& b) {
             return centroid3(a, best_axis) < centroid3(b, best_axis);

@@ -800,7 +800,9 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
                     }
                     float step = (hi - lo) / 255.0f;
                     if (!(step > 0.0f) || !(step < std::numeric_limits<float>::max())) step = 0.0f;
-                    while (step > 0.0f && lo + step * 255.0f < hi) step = std::nextafter(step, std::numeric_limits<float>::max());
+                    // (far from the origin one unit in the last place of `hi` is many of `step`: grow geometrically)
+                    for (float grow = 1.0f / 1024.0f; step > 0.0f && lo + step * 255.0f < hi; grow *= 2.0f)
+                        step = std::max(std::nextafter(step, std::numeric_limits<float>::max()), step * (1.0f + grow));
                     nd.origin[a] = lo;
                     nd.scale[a] = step;
                     for (int k = 0; k < n_ch; ++k) {

@@ -382,6 +382,42 @@ def sparse_clouds(n_objects: int = 14, tris_per_object: int = 60, seed: int = 5)
     return b.build()
 
 
+def random_soup(seed: int, n_objects: int = 5, tris_per_object: int = 4000, offset: float = 0.0, flat: bool = False) -> SceneModel:
+    """Triangle soups under random affine transforms (rotation, non-uniform scale, shear): no structure a builder or a
+    node layout could rely on.  ``offset`` moves every mesh far from its object-space origin (large coordinates, small
+    extents: box planes and quantisation steps lose bits); ``flat`` adds axis-aligned quads (boxes of zero thickness)."""
+    rng = np.random.default_rng(seed)
+    b = ModelBuilder(f"random_soup_{seed}")
+    for k in range(n_objects):
+        mat = b.add_material(base_color=tuple(rng.uniform(0.2, 0.9, 3)) + (1.0,), metallic=float(k % 2), roughness=0.5,
+                             double_sided=(k % 2 == 0))
+        centres = rng.uniform(-1.0, 1.0, (tris_per_object, 1, 3)) * rng.uniform(0.3, 1.0, 3)
+        size = rng.choice([0.01, 0.05, 0.3], (tris_per_object, 1, 1))
+        pos = (centres + rng.normal(size=(tris_per_object, 3, 3)) * size)
+        if flat:
+            q = rng.uniform(-1, 1, (tris_per_object // 4, 1, 3))
+            axis = rng.integers(0, 3, len(q))
+            e = rng.uniform(0.05, 0.4, (len(q), 3, 3)) * np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]])[None]
+            quad = q + e
+            for a in range(3):  # rotate the in-plane axes so that the flat axis is `a`
+                sel = axis == a
+                quad[sel] = np.roll(quad[sel], a + 1, axis=2)
+            pos = np.concatenate([pos, quad])
+        pos = (pos + offset).reshape(-1, 3).astype(np.float32)
+        tri = pos.reshape(-1, 3, 3)
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        n = np.repeat(_normalize(n + 1e-20), 3, axis=0).astype(np.float32)
+        mesh = b.add_mesh(pos, n, np.arange(len(pos), dtype=np.uint32), material=mat)
+        m = np.eye(4)
+        a = rng.normal(size=(3, 3))
+        qm, _ = np.linalg.qr(a)
+        m[:3, :3] = qm @ np.diag(rng.uniform(0.4, 1.6, 3)) @ (np.eye(3) + np.triu(rng.uniform(-0.2, 0.2, (3, 3)), 1))
+        m[:3, 3] = rng.uniform(-0.5, 0.5, 3) - m[:3, :3] @ np.full(3, offset)
+        b.add_object(mesh, m)
+    b.add_camera(Camera((0.0, 0.2, 5.0), (0.0, -0.03, -1.0), (0.0, 1.0, 0.0), np.radians(45.0), 0.1, 100.0))
+    return b.build()
+
+
 def tiny_scene(seed: int = 3) -> SceneModel:
     """A few hundred triangles exercising every material feature; small enough for the CPU oracle in tests."""
     return readme_standin(detail=0.03, seed=seed)

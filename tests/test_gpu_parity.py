@@ -270,6 +270,37 @@ def test_wide_nodes_give_the_same_results(tiny, materials, scene, as_type):
     assert exact.mean() >= 0.9999
 
 
+@pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
+def test_random_soups_both_node_layouts(seed, offset, flat):
+    """Unstructured triangle soups under random affine transforms, also far from the object-space origin (box planes and
+    the four-wide nodes' quantisation steps lose bits there) and with zero-thickness boxes: closest hits of camera rays
+    and of random rays must be the oracle's on both node layouts, on host-built and device-built trees; occlusion flags
+    too.  A box that failed to contain its triangles would show up here as hits turned into misses."""
+    model = scenes.random_soup(seed, offset=offset, flat=flat)
+    w, h = 256, 144
+    o = H.make_oracle(model, None, H.settings(program=0), w, h)
+    ref = o.render_hits(w, h)
+    rng = np.random.default_rng(seed)
+    n = 30000
+    org = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(-1, 1, (n, 3))
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    ref_rays = o.intersect_rays(org, d)
+    flags = np.ones(n, np.uint8)
+    ref_occ = o.intersect_rays(org, d, flags)["hit"]
+    assert (ref["hit"] != 0).mean() > 0.05 and (ref_rays["hit"] != 0).mean() > 0.2
+    for as_type, wide in ((1, False), (1, True), (2, False), (2, True)):
+        g = H.make_gpu(model, None, H.settings(program=0, as_type=as_type, wide=wide), w, h)
+        need = 1.0 if (as_type == 1 and not wide) else 0.9999
+        exact, _ = H.hits_equal(ref, g.render_hits(w, h))
+        assert exact.mean() >= need, (as_type, wide, int((~exact).sum()))
+        exact, _ = H.hits_equal(ref_rays, g.intersect_rays(org, d))
+        assert exact.mean() >= need, (as_type, wide, int((~exact).sum()))
+        assert (g.intersect_rays(org, d, flags)["hit"] == ref_occ).mean() >= need, (as_type, wide)
+        del g
+
+
 def test_golden_converged_images(tiny, golden):
     model, env = tiny
     w, h = 64, 36
