@@ -35,7 +35,10 @@ struct HitQueue {
 
 // Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot);
 // a slot of PT_NO_NODE ends the list; at most kCandMax entries are stored (longer lists are continued by a rescan).
-constexpr int kCandMax = 8;
+#ifndef PT_CAND_MAX
+#define PT_CAND_MAX 8
+#endif
+constexpr int kCandMax = PT_CAND_MAX;
 struct CandQueue {
     uint2* e;
     uint32_t stride;
