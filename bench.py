@@ -108,6 +108,8 @@ def main() -> None:
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--single-path", action="store_true", help="PBR: one spawned ray per hit (same expectation)")
+    ap.add_argument("--split", choices=("samples", "tiles"), default="samples",
+                    help="how N > 1 ranks share the frame: disjoint samples of every pixel, or disjoint 8x8 tiles")
     ap.add_argument("--binary-nodes", action="store_true",
                     help="traverse the binary nodes in the reference's visiting order instead of the four-wide quantised nodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -151,8 +153,8 @@ def main() -> None:
     model = build_scene(cfg["scene"], args.detail, args.stress_tris)
     env = load_env(cfg["env"])
     w, h = cfg["width"], cfg["height"]
-    from pathtracer_amd.distributed import combine_partial_sums, subset_settings
-    settings = subset_settings(RenderSettings(cfg["spp"], cfg["bounces"], cfg["newrays"], 8, 0.0,
+    from pathtracer_amd.distributed import combine_partial_sums, subset_settings, subset_tiles
+    settings = (subset_tiles if args.split == "tiles" else subset_settings)(RenderSettings(cfg["spp"], cfg["bounces"], cfg["newrays"], 8, 0.0,
                                               RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
                                               singlePath=bool(cfg.get("single")), wideNodes=not args.binary_nodes),
                                rank, world)
@@ -233,7 +235,7 @@ def main() -> None:
                             f"{'binary' if args.binary_nodes else 'four-wide quantised'} nodes, "
                             f"{model.instanced_triangles()} instanced triangles, "
                             f"{len(model.objects)} objects",
-                "parallelism": f"sample-split x{world}" + ((" + RCCL" if backend == "nccl" else f" + {backend}") + " reduce(sum) to rank 0" if world > 1 else ""),
+                "parallelism": f"{'tile' if args.split == 'tiles' else 'sample'}-split x{world}" + ((" + RCCL" if backend == "nccl" else f" + {backend}") + " reduce(sum) to rank 0" if world > 1 else ""),
                 "scene_load_s": round(t_load, 2),
             },
         }

@@ -142,6 +142,8 @@ typedef struct ptgpu_settings {
     uint32_t sample_begin; /* first global sample index rendered here (default 0) */
     uint32_t sample_step;  /* stride between rendered sample indices (default 1; 0 means 1) */
     uint32_t flags;        /* PTGPU_FLAG_*, default 0 */
+    uint32_t tile_begin;   /* multi-GPU tile split: first 8x8-pixel tile (row-major tile index) rendered here (default 0) */
+    uint32_t tile_step;    /* stride between rendered tiles (default 1; 0 means 1); pixels of other tiles stay 0 */
 } ptgpu_settings;
 
 /* PBR only, no counterpart in the reference (whose estimator follows every lobe

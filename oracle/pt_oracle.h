@@ -104,6 +104,7 @@ typedef struct orc_settings {
     uint32_t sample_begin;
     uint32_t sample_step;
     uint32_t flags; /* ORC_FLAG_* */
+    uint32_t tile_begin, tile_step; /* layout of the GPU library's settings; the oracle always renders every tile */
 } orc_settings;
 #define ORC_FLAG_SINGLE_PATH 1u /* PBR keeps one of the rays a hit would spawn (see Programs::pbr_single) */
 

@@ -87,6 +87,8 @@ class Settings(C.Structure):
         ("sample_begin", C.c_uint32),
         ("sample_step", C.c_uint32),
         ("flags", C.c_uint32),
+        ("tile_begin", C.c_uint32),
+        ("tile_step", C.c_uint32),
     ]
 
 

@@ -67,9 +67,13 @@ struct TraceCounters {   // filled by the counting variant of extend
 
 // slots_in_batch == 0: camera samples [first, first + n) of the linear index (sample_slot * n_tiles + tile) * 64 + lane.
 // slots_in_batch == S: sample slots [first, first + S) of every tile in tile-major order, n = S * n_tiles * 64.
+// The 8x8-pixel tiles a context renders: begin, begin + step, ... (count of them); {0, 1, all tiles} = the whole frame.
+struct TileSubset {
+    uint32_t begin, step, count;
+};
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
-                     uint32_t slots_in_batch, RayQueue out, uint32_t* out_count);
+                     uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count);
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters);
 // Workgroups that are resident at once for the persistent extend kernel (occupancy x compute units).

@@ -943,13 +943,13 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t*
 __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const float2* __restrict__ sub,
                                                           uint32_t sample_begin, uint32_t sample_step,
                                                           uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
-                                                          uint32_t slots_in_batch, RayQueue out,
-                                                          uint32_t* __restrict__ out_count) {
+                                                          uint32_t slots_in_batch, uint32_t tile_begin, uint32_t tile_step,
+                                                          uint32_t n_tiles, RayQueue out, uint32_t* __restrict__ out_count) {
+    // n_tiles = tiles rendered here: tile_begin, tile_begin + tile_step, ... (all of them when 0 / 1)
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     bool valid = false;
     float4 o4, d4, p4;
     if (i < n) {
-        const uint32_t n_tiles = static_cast<uint32_t>(cam.tiles_x) * cam.tiles_y;
         uint32_t lane, tile, slot;
         if (slots_in_batch) {
             // batch = sample slots [first, first + slots_in_batch) of every tile, TILE-major: all samples of a tile
@@ -966,6 +966,7 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
             tile = static_cast<uint32_t>(tile_lin % n_tiles);
             slot = static_cast<uint32_t>(tile_lin / n_tiles);
         }
+        tile = tile_begin + tile * tile_step;
         const uint32_t sample = sample_begin + slot * sample_step;
         const int x = static_cast<int>((tile % cam.tiles_x) * kTile + (lane & 7u));
         const int y = static_cast<int>((tile / cam.tiles_x) * kTile + (lane >> 3));
@@ -1585,10 +1586,10 @@ inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + kBloc
 
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
-                     uint32_t slots_in_batch, RayQueue out, uint32_t* out_count) {
+                     uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count) {
     if (!n) return;
     hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
-                       sample_step, max_bounces, seed, first, n, slots_in_batch, out, out_count);
+                       sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
 }
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters) {

@@ -310,8 +310,12 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     // Camera samples are generated in equal batches of at most `chunk`; a batch is also the largest launch.  A batch
     // is a range of whole sample slots of every tile whenever one slot of the frame fits a chunk (tile-major queue
     // order, see generate_kernel); frames larger than that fall back to ranges of the linear sample-major index.
-    const uint64_t total = static_cast<uint64_t>(n_slots) * g.n_tiles * 64ull;
-    const uint64_t per_slot = static_cast<uint64_t>(g.n_tiles) * 64ull;
+    // tile split (multi-GPU alternative to the sample split): only tiles tile_begin, tile_begin + tile_step, ... are rendered
+    const uint32_t tile_step = s.tile_step ? s.tile_step : 1;
+    const ptd::TileSubset tiles{s.tile_begin, tile_step,
+                                s.tile_begin < g.n_tiles ? (g.n_tiles - s.tile_begin + tile_step - 1) / tile_step : 0u};
+    const uint64_t total = static_cast<uint64_t>(n_slots) * tiles.count * 64ull;
+    const uint64_t per_slot = static_cast<uint64_t>(tiles.count) * 64ull;
     uint32_t slots_per_batch = 0;
     uint64_t K;
     if (per_slot <= c->chunk && n_slots) {
@@ -376,9 +380,9 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         if (slots_per_batch) {
             const uint32_t slot0 = static_cast<uint32_t>(first / per_slot);
             ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, slot0, n_gen,
-                                 static_cast<uint32_t>(n_gen / per_slot), gp.at(gp.top), d_count);
+                                 static_cast<uint32_t>(n_gen / per_slot), tiles, gp.at(gp.top), d_count);
         } else {
-            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, gp.at(gp.top),
+            ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, tiles, gp.at(gp.top),
                                  d_count);
         }
         PT_HIP(c, hipEventRecord(c->ev[1], st));
@@ -557,6 +561,7 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
     d.program_mode = PTGPU_PROGRAM_PBR;
     d.accel_struct_type = PTGPU_AS_BVH;
     d.sample_step = 1;
+    d.tile_step = 1;
     ctx->settings = d;
     if (const char* m = std::getenv("PTGPU_EXTEND")) ctx->persistent = std::strcmp(m, "simple") != 0;
     if (const char* k = std::getenv("PTGPU_CHUNK")) {
@@ -1127,8 +1132,8 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     for (uint64_t first = 0; first < total; first += K) {
         const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
         PT_HIP(c, hipMemsetAsync(c->counter.p, 0, 4, st));
-        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, 0, c->pools[0].at(0),
-                             c->counter.as<uint32_t>());
+        ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, 0,
+                             ptd::TileSubset{0u, 1u, g.n_tiles}, c->pools[0].at(0), c->counter.as<uint32_t>());
         PT_HIP(c, hipMemcpyAsync(c->host_counter, c->counter.p, 4, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipStreamSynchronize(st));
         const uint32_t n = *c->host_counter;

@@ -1,5 +1,5 @@
-"""Multi-GPU sample split: one process per GPU, each renders a disjoint subset of the samples of every
-pixel; the partial per-pixel sums are combined with one reduce(sum) to rank 0 (RCCL over xGMI when the
+"""Multi-GPU split: one process per GPU, each renders a disjoint subset of the samples of every
+pixel (or, `subset_tiles`, every sample of a disjoint subset of the 8x8-pixel tiles); the partial per-pixel sums are combined with one reduce(sum) to rank 0 (RCCL over xGMI when the
 tensors are on GPUs; the same code runs over gloo on CPU tensors in the tests).
 
 Rank g of G renders the global sample indices g, g + G, g + 2G, ...  The sub-pixel table and the
@@ -22,6 +22,15 @@ def subset_settings(settings: RenderSettings, rank: int, world: int) -> RenderSe
     if world < 1 or not (0 <= rank < world):
         raise ValueError(f"bad rank/world {rank}/{world}")
     return replace(settings, sampleBegin=rank, sampleStep=world)
+
+
+def subset_tiles(settings: RenderSettings, rank: int, world: int) -> RenderSettings:
+    """The alternative split for high resolutions / few samples: rank `rank` renders every sample of the 8x8-pixel
+    tiles rank, rank + world, ... (interleaved, so that every rank sees every part of the picture) and leaves the other
+    pixels at zero — the same reduce(sum) combines the ranks, each pixel receiving exactly one non-zero term."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    return replace(settings, tileBegin=rank, tileStep=world)
 
 
 def samples_of_rank(total_spp: int, rank: int, world: int) -> int:

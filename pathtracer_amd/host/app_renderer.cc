@@ -417,6 +417,8 @@ void Renderer::push_settings() {
     s.sample_begin = 0;
     s.sample_step = 1;
     s.flags = (single_path_ ? PTGPU_FLAG_SINGLE_PATH : 0u) | (wide_nodes_ ? PTGPU_FLAG_WIDE_NODES : 0u);
+    s.tile_begin = 0;
+    s.tile_step = 1;
     const int rc = ptgpu_set_render_settings(ctx_, &s);
     if (rc != PTGPU_OK) fail("ptgpu_set_render_settings", rc);
 }

@@ -46,19 +46,22 @@ class RenderSettings:
     sampleStep: int = 1
     singlePath: bool = False  # PBR keeps one of the rays a hit would spawn (same expectation, at most one ray per hit)
     wideNodes: bool = False   # read at load_scene: four-wide quantised nodes (same closest hits, about half the node visits)
+    tileBegin: int = 0        # tile split: 8x8 tiles tileBegin, tileBegin + tileStep, ... are rendered, the others stay 0
+    tileStep: int = 1
 
     def to_abi(self) -> abi.Settings:
         return abi.Settings(self.samplesPerPixel, self.maxRayBounces, self.maxNewRaysPerBounce,
                             self.maxTrianglesPerBVHLeaf, self.envmapRotation, int(self.programMode),
                             int(self.accelStructType), self.seed, self.sampleBegin, self.sampleStep,
-                            (abi.FLAG_SINGLE_PATH if self.singlePath else 0) | (abi.FLAG_WIDE_NODES if self.wideNodes else 0))
+                            (abi.FLAG_SINGLE_PATH if self.singlePath else 0) | (abi.FLAG_WIDE_NODES if self.wideNodes else 0),
+                            self.tileBegin, self.tileStep)
 
     @staticmethod
     def from_abi(s: abi.Settings) -> "RenderSettings":
         return RenderSettings(s.samples_per_pixel, s.max_ray_bounces, s.max_new_rays_per_bounce,
                               s.max_triangles_per_bvh_leaf, s.envmap_rotation, RayProgramMode(s.program_mode),
                               AccelerationStructureType(s.accel_struct_type), s.seed, s.sample_begin, s.sample_step,
-                              bool(s.flags & abi.FLAG_SINGLE_PATH), bool(s.flags & abi.FLAG_WIDE_NODES))
+                              bool(s.flags & abi.FLAG_SINGLE_PATH), bool(s.flags & abi.FLAG_WIDE_NODES), s.tile_begin, s.tile_step or 1)
 
 
 @dataclass

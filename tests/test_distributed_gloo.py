@@ -5,6 +5,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -65,3 +66,20 @@ def test_subset_settings_partition_the_samples():
             seen += list(range(s.sampleBegin, 300, s.sampleStep))
             assert samples_of_rank(300, r, world) == len(range(r, 300, world))
         assert sorted(seen) == list(range(300))
+
+
+def test_subset_tiles_partition_the_tiles():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from pathtracer_amd.distributed import subset_tiles
+    st = H.settings(spp=16)
+    n_tiles = ((3840 + 7) // 8) * ((2160 + 7) // 8)
+    for world in (1, 2, 4, 8):
+        seen = 0
+        for r in range(world):
+            s = subset_tiles(st, r, world)
+            assert (s.sampleBegin, s.sampleStep) == (0, 1) and s.to_abi().tile_step == world
+            seen += len(range(s.tileBegin, n_tiles, s.tileStep))
+        assert seen == n_tiles
+    with pytest.raises(ValueError):
+        subset_tiles(st, 2, 2)

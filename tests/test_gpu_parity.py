@@ -350,6 +350,34 @@ def test_sample_split_partial_sums_add_up(tiny):
     assert np.allclose(img.cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
 
 
+def test_tile_split_partial_frames_add_up(tiny):
+    """The tile split: every rank renders all samples of its own 8x8 tiles and leaves the rest at zero, so the sum over
+    ranks is the frame — each pixel gets one non-zero term, hence EQUAL to that rank's value, and within the
+    framebuffer's summation-order tolerance of a single-context render."""
+    import torch
+    from pathtracer_amd.distributed import subset_tiles
+    model, env = tiny
+    w, h, spp, world = 100, 60, 6, 3   # 13 x 8 tiles, the last column and row partial
+    st = H.settings(program=2, spp=spp, bounces=3)
+    g = H.make_gpu(model, env, st, w, h)
+    full, s_full = H.gpu_render(g, w, h)
+    parts, rays, samples = [], 0, 0
+    for rank in range(world):
+        g.set_render_settings(subset_tiles(st, rank, world))
+        buf = torch.zeros((h, w, 4), device="cuda")
+        s = g.render_frame_sums(w, h, buf.data_ptr())
+        parts.append(buf.cpu().numpy())
+        rays += s.rays
+        samples += s.camera_samples
+    assert rays == s_full.rays and samples == s_full.camera_samples == w * h * spp
+    tile_of = (np.arange(h)[:, None] // 8) * ((w + 7) // 8) + (np.arange(w)[None, :] // 8)
+    for rank, p in enumerate(parts):
+        mine = (tile_of % world) == rank
+        assert (p[~mine][:, :3] == 0).all() and np.abs(p[mine][:, :3]).sum() > 0
+    total = sum(parts)[..., :3] / spp
+    assert np.allclose(total, full[..., :3], rtol=1e-5, atol=1e-6)
+
+
 def test_edge_cases():
     from pathtracer_amd.model import ModelBuilder, Camera
     env = scenes.synthetic_env(16, 8)

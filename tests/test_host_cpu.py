@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(abi.Vertex) == 48 and C.sizeof(abi.Mesh) == 20 and C.sizeof(abi.Object) == 132
     assert C.sizeof(abi.Material) == 100 and C.sizeof(abi.Image) == 16 and C.sizeof(abi.Hit) == 32
-    assert C.sizeof(abi.Settings) == 44
+    assert C.sizeof(abi.Settings) == 52
 
 
 @pytest.mark.skipif(not _no_gpu(), reason="checks the no-GPU failure path")
