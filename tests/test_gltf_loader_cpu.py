@@ -264,3 +264,62 @@ def test_tangents_survive_degenerate_and_unmapped_triangles(lib):
     uv0 = np.zeros_like(uv)                                   # no uv area anywhere: the library's default tangent space
     t0 = tangents(lib, pos, nrm, uv0, tris)
     assert np.isfinite(t0).all() and np.allclose(t0[:, :3], [1.0, 0.0, 0.0]) and (t0[:, 3] == -1.0).all()
+
+
+def test_loaders_survive_mutated_files(tmp_path):
+    """Corrupted input must end in an error return, never in a crash or a hang: 120 seeded mutations (byte flips in the
+    JSON chunk, in the binary chunk and header, truncations) of a GLB, of PNG / JPEG streams and of a scene container,
+    read in a child process."""
+    import random
+    import subprocess
+    import sys
+    rng = random.Random(7)
+    glb = tmp_path / "s.glb"
+    gltf_export.save_glb(scenes.tiny_scene(), str(glb))
+    ptsc = tmp_path / "s.ptsc"
+    scenes.tiny_scene().save(str(ptsc))
+    img = (np.random.default_rng(0).uniform(0, 255, (23, 31, 3))).astype(np.uint8)
+    seeds = {"glb": glb.read_bytes(), "ptsc": ptsc.read_bytes()}
+    for fmt, kw in (("PNG", {}), ("JPEG", {"quality": 80, "subsampling": 2})):
+        b = io.BytesIO()
+        PIL.fromarray(img).save(b, fmt, **kw)
+        seeds[fmt.lower()] = b.getvalue()
+    paths = []
+    for name, data in seeds.items():
+        json_len = struct.unpack_from("<I", data, 12)[0] if name == "glb" else 0
+        for k in range(30):
+            m = bytearray(data)
+            kind = rng.random()
+            if kind < 0.4 and json_len:
+                for _ in range(rng.randint(1, 4)):
+                    m[rng.randrange(20, 20 + json_len)] = rng.choice(b'0123456789-[]{}",:ae ')
+            elif kind < 0.8:
+                for _ in range(rng.randint(1, 8)):
+                    m[rng.randrange(len(m))] = rng.randrange(256)
+            else:
+                m = m[:rng.randrange(1, len(m))]
+            p = tmp_path / f"{name}_{k}.{'glb' if name == 'glb' else name}"
+            p.write_bytes(m)
+            paths.append(str(p))
+    child = r"""
+import ctypes as C, sys
+sys.path.insert(0, sys.argv[1])
+import pathtracer_amd._lib
+L = C.CDLL(sys.argv[2])
+L.ptapp_convert_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t]
+L.ptapp_decode_image.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p,
+                                 C.c_size_t, C.c_char_p, C.c_size_t]
+err = C.create_string_buffer(256)
+for p in sys.argv[3:]:
+    if p.endswith((".glb", ".ptsc")):
+        L.ptapp_convert_scene(p.encode(), (p + ".out").encode(), err, 256)
+    else:
+        data = open(p, "rb").read()
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        if L.ptapp_decode_image(data, len(data), w, h, ch, None, 0, err, 256) == 0 and 0 < w.value * h.value < 1 << 24:
+            buf = C.create_string_buffer(w.value * h.value * 4)
+            L.ptapp_decode_image(data, len(data), w, h, ch, buf, len(buf), err, 256)
+print("done")
+"""
+    r = subprocess.run([sys.executable, "-c", child, ROOT, LIB] + paths, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.strip().endswith("done"), (r.returncode, r.stderr[-400:])
