@@ -920,8 +920,9 @@ __global__ __launch_bounds__(kBlock) void extend_overflow_kernel(SceneDev sc, co
 // Reserves `wave_total` consecutive queue slots for the calling wavefront with ONE atomic per workgroup: a single
 // counter word sustains well under 100 M atomics/s, which one atomic per wavefront would exceed at the
 // kernel's ray rate.  Every thread of the workgroup must call it.
+template <int BLOCK = kBlock>
 __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t* out_count) {
-    __shared__ uint32_t s_tot[kBlock / 64];
+    __shared__ uint32_t s_tot[BLOCK / 64];
     __shared__ uint32_t s_base;
     const uint32_t wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63u) == 0) s_tot[wave] = wave_total;
@@ -929,13 +930,13 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t*
     if (threadIdx.x == 0) {
         uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) t += s_tot[w];
+        for (int w = 0; w < BLOCK / 64; ++w) t += s_tot[w];
         s_base = t ? atomicAdd(out_count, t) : 0u;
     }
     __syncthreads();
     uint32_t base = s_base;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w)
+    for (int w = 0; w < BLOCK / 64; ++w)
         if (static_cast<uint32_t>(w) < wave) base += s_tot[w];
     return base;
 }
@@ -1039,9 +1040,11 @@ __shared__ float s_unorm_lut[256];
 constexpr uint32_t kObjLds = 16;
 __shared__ float4 s_objects[kObjLds * (sizeof(DevObject) / 16)];
 __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
-    static_assert(kBlock == 256, "one table entry per thread");
-    s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
-    s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
+    static_assert(kBlock >= 256, "one table entry per thread (of the first 256)");
+    if (threadIdx.x < 256u) {
+        s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
+        s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
+    }
     const uint32_t n_quarters = (sc.n_instances < kObjLds ? sc.n_instances : kObjLds) * (sizeof(DevObject) / 16);
     if (threadIdx.x < n_quarters) s_objects[threadIdx.x] = reinterpret_cast<const float4*>(sc.objects)[threadIdx.x];
     __syncthreads();
@@ -1330,10 +1333,17 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
 // ---------------------------------------------------------------------------------------------
 // shade: PBR (ray_program.cc:234-391)
 // ---------------------------------------------------------------------------------------------
+// Threads per workgroup of the PBR shading kernel.  One queue-reservation atomic per workgroup: at 256 threads a launch of
+// 74 M rays issues 290 K of them in 3.7 ms, close to what one counter word sustains (~85 M/s) — but larger workgroups are
+// slower all the same (512: +5 %, 1024: +24 %: the two barriers of the reservation weigh more), so 256 it stays.
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256
+#endif
+constexpr int kShadeBlock = PT_SHADE_BLOCK;
 #ifdef PT_SHADE_WAVES
-#define PT_SHADE_BOUNDS __launch_bounds__(kBlock, PT_SHADE_WAVES)
+#define PT_SHADE_BOUNDS __launch_bounds__(kShadeBlock, PT_SHADE_WAVES)
 #else
-#define PT_SHADE_BOUNDS __launch_bounds__(kBlock)
+#define PT_SHADE_BOUNDS __launch_bounds__(kShadeBlock)
 #endif
 // Largest component of a payload as a selection weight; NaN, infinite and zero payloads are never chosen.
 __device__ __forceinline__ float lobe_weight(f3 p) {
@@ -1355,7 +1365,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     // probability proportional to the largest component of its payload, payload divided by that probability — and
     // the reservation is for that one ray.
     stage_decode_tables(sc);
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
     // state that survives from stage A to stage C
     float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro;
@@ -1511,7 +1521,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             offs[s] = total + __popcll(mask & lt);
             total += __popcll(mask);
         }
-        const uint32_t base = block_reserve(total, out_count);
+        const uint32_t base = block_reserve<kShadeBlock>(total, out_count);
         lobes([&](auto s, f3 org, float4 d4, f3 pl, uint32_t lobe) { store(base + offs[decltype(s)::value], org, d4, pl, lobe); });
     } else {
         f3 org0 = mk3(0.0f), org1 = org0, org2 = org0, org3 = org0, pl0 = org0, pl1 = org0, pl2 = org0, pl3 = org0;
@@ -1542,7 +1552,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const float4 d4 = (pick == 0) ? d0 : (pick == 1) ? d1 : (pick == 2) ? d2 : d3;
         const f3 pl = (pick == 0) ? pl0 : (pick == 1) ? pl1 : (pick == 2) ? pl2 : pl3;
         const unsigned long long mask = __ballot(any);
-        const uint32_t base = block_reserve(__popcll(mask), out_count);
+        const uint32_t base = block_reserve<kShadeBlock>(__popcll(mask), out_count);
         if (any) store(base + __popcll(mask & lt), org, d4, pl * (total_w / wp), static_cast<uint32_t>(pick));
     }
 }
@@ -1649,9 +1659,11 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
     if (program == 1)
         hipLaunchKernelGGL(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
     else if (program == 2 && single_path)
-        hipLaunchKernelGGL(shade_pbr_kernel<true>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
+        hipLaunchKernelGGL(shade_pbr_kernel<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
+                           out, out_count, fb);
     else if (program == 2)
-        hipLaunchKernelGGL(shade_pbr_kernel<false>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb);
+        hipLaunchKernelGGL(shade_pbr_kernel<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
+                           out, out_count, fb);
     else
         hipLaunchKernelGGL(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
 }
