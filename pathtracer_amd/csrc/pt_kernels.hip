@@ -941,6 +941,9 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t*
     return base;
 }
 
+// DENSE: the frame is a whole number of tiles, so every lane has a pixel and ray i goes to slot i — no compaction, no
+// queue atomic (one per workgroup is ~100 M/s at this kernel's rate, more than one counter word sustains).
+template <bool DENSE>
 __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const float2* __restrict__ sub,
                                                           uint32_t sample_begin, uint32_t sample_step,
                                                           uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
@@ -990,6 +993,15 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
             d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float(max_bounces & 0xffu));
             p4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_camera_key(seed, pixel, sample)));
         }
+    }
+    if (DENSE) {
+        if (valid) {
+            out.o[i] = o4;
+            out.d[i] = d4;
+            out.p[i] = p4;
+        }
+        if (i == 0) *out_count = n;
+        return;
     }
     // compaction: rays of a wave stay contiguous and ordered
     const unsigned long long mask = __ballot(valid);
@@ -1598,8 +1610,12 @@ void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamp
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
                      uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count) {
     if (!n) return;
-    hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
-                       sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
+    if (cam.width % kTile == 0 && cam.height % kTile == 0)
+        hipLaunchKernelGGL(generate_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
+                           sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
+    else
+        hipLaunchKernelGGL(generate_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
+                           sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
 }
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters) {
