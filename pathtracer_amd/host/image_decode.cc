@@ -49,7 +49,7 @@ DecodedImage decode_png(const uint8_t* data, size_t size) {
         pos += 12ull + len;
     }
     if (!w || !h || w > (1u << 24) || h > (1u << 24)) bad("bad PNG size");
-    if (interlace) bad("interlaced PNG is not supported");
+    if (interlace > 1) bad("bad PNG interlace method");
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -63,76 +63,105 @@ DecodedImage decode_png(const uint8_t* data, size_t size) {
     if ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) bad("bad PNG bit depth for its colour type");
     if (ctype == 3 && (depth == 16 || palette.empty())) bad("bad PNG palette");
     const size_t bits_per_pixel = static_cast<size_t>(channels) * depth;
-    const size_t row_bytes = (bits_per_pixel * w + 7) / 8;
     const size_t bpp = std::max<size_t>(1, bits_per_pixel / 8);  // filter distance
-    std::vector<uint8_t> raw((row_bytes + 1) * h);
+    // The picture is one pass over all pixels, or the seven Adam7 passes (each a reduced picture of every dx-th column
+    // and dy-th row starting at (x0, y0)), stored one after the other in the data stream.
+    struct Pass {
+        uint32_t x0, y0, dx, dy;
+    };
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass whole[1] = {{0, 0, 1, 1}};
+    const Pass* passes = interlace ? adam7 : whole;
+    const int n_passes = interlace ? 7 : 1;
+    auto pass_size = [&](const Pass& ps, uint32_t& pw, uint32_t& ph) -> size_t {
+        pw = ps.x0 < w ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0;
+        ph = ps.y0 < h ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        return (pw && ph) ? ((bits_per_pixel * pw + 7) / 8 + 1) * ph : 0;
+    };
+    size_t raw_size = 0;
+    for (int k = 0; k < n_passes; ++k) {
+        uint32_t pw, ph;
+        raw_size += pass_size(passes[k], pw, ph);
+    }
+    std::vector<uint8_t> raw(raw_size);
     uLongf out_len = static_cast<uLongf>(raw.size());
     if (uncompress(raw.data(), &out_len, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || out_len != raw.size())
         bad("corrupt PNG data stream");
-    // undo the scanline filters in place
-    std::vector<uint8_t> zero(row_bytes, 0);
-    for (uint32_t y = 0; y < h; ++y) {
-        uint8_t* row = raw.data() + y * (row_bytes + 1);
-        const int filter = row[0];
-        uint8_t* cur = row + 1;
-        const uint8_t* up = y ? raw.data() + (y - 1) * (row_bytes + 1) + 1 : zero.data();
-        for (size_t i = 0; i < row_bytes; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-            int pred = 0;
-            switch (filter) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) >> 1; break;
-                case 4: {
-                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
-                }
-                default: bad("bad PNG filter");
-            }
-            cur[i] = static_cast<uint8_t>(cur[i] + pred);
-        }
-    }
     DecodedImage img;
     img.width = static_cast<int>(w);
     img.height = static_cast<int>(h);
     img.channels = (ctype == 3) ? (trns.empty() ? 3 : 4) : channels;
     img.rgba.resize(static_cast<size_t>(w) * h * 4);
     const int scale_small[5] = {0, 255, 85, 0, 17};  // 1-, 2- and 4-bit gray samples stretched to 0..255
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* row = raw.data() + y * (row_bytes + 1) + 1;
-        for (uint32_t x = 0; x < w; ++x) {
-            uint32_t s[4] = {0, 0, 0, 0};  // raw samples of this pixel
-            for (int c = 0; c < channels; ++c) {
-                const size_t idx = static_cast<size_t>(x) * channels + c;
-                if (depth == 8) s[c] = row[idx];
-                else if (depth == 16) s[c] = be16(row + idx * 2);
-                else {
-                    const size_t bit = idx * depth;
-                    s[c] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+    size_t offset = 0;
+    for (int k = 0; k < n_passes; ++k) {
+        const Pass& ps = passes[k];
+        uint32_t pw, ph;
+        const size_t bytes = pass_size(ps, pw, ph);
+        if (!bytes) continue;
+        uint8_t* base = raw.data() + offset;
+        offset += bytes;
+        const size_t row_bytes = (bits_per_pixel * pw + 7) / 8;
+        // undo the scanline filters in place
+        std::vector<uint8_t> zero(row_bytes, 0);
+        for (uint32_t y = 0; y < ph; ++y) {
+            uint8_t* row = base + y * (row_bytes + 1);
+            const int filter = row[0];
+            uint8_t* cur = row + 1;
+            const uint8_t* up = y ? base + (y - 1) * (row_bytes + 1) + 1 : zero.data();
+            for (size_t i = 0; i < row_bytes; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
+                int pred = 0;
+                switch (filter) {
+                    case 0: pred = 0; break;
+                    case 1: pred = a; break;
+                    case 2: pred = b; break;
+                    case 3: pred = (a + b) >> 1; break;
+                    case 4: {
+                        const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                        break;
+                    }
+                    default: bad("bad PNG filter");
                 }
+                cur[i] = static_cast<uint8_t>(cur[i] + pred);
             }
-            uint8_t* o = img.rgba.data() + (static_cast<size_t>(y) * w + x) * 4;
-            auto to8 = [&](uint32_t v) -> uint8_t {
-                if (depth == 16) return static_cast<uint8_t>(v >> 8);
-                if (depth < 8) return static_cast<uint8_t>(v * scale_small[depth]);
-                return static_cast<uint8_t>(v);
-            };
-            if (ctype == 3) {
-                if (s[0] * 3 + 2 >= palette.size()) bad("PNG palette index out of range");
-                o[0] = palette[s[0] * 3]; o[1] = palette[s[0] * 3 + 1]; o[2] = palette[s[0] * 3 + 2];
-                o[3] = s[0] < trns.size() ? trns[s[0]] : 255;
-            } else if (ctype == 0 || ctype == 4) {
-                o[0] = o[1] = o[2] = to8(s[0]);
-                o[3] = (ctype == 4) ? to8(s[1]) : 255;
-                if (ctype == 0 && trns.size() >= 2 && s[0] == be16(trns.data())) o[3] = 0;
-            } else {
-                o[0] = to8(s[0]); o[1] = to8(s[1]); o[2] = to8(s[2]);
-                o[3] = (ctype == 6) ? to8(s[3]) : 255;
-                if (ctype == 2 && trns.size() >= 6 && s[0] == be16(trns.data()) && s[1] == be16(trns.data() + 2) &&
-                    s[2] == be16(trns.data() + 4))
-                    o[3] = 0;
+        }
+        for (uint32_t py = 0; py < ph; ++py) {
+            const uint8_t* row = base + py * (row_bytes + 1) + 1;
+            for (uint32_t px = 0; px < pw; ++px) {
+                uint32_t s[4] = {0, 0, 0, 0};  // raw samples of this pixel
+                for (int c = 0; c < channels; ++c) {
+                    const size_t idx = static_cast<size_t>(px) * channels + c;
+                    if (depth == 8) s[c] = row[idx];
+                    else if (depth == 16) s[c] = be16(row + idx * 2);
+                    else {
+                        const size_t bit = idx * depth;
+                        s[c] = (row[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                    }
+                }
+                const uint32_t x = ps.x0 + px * ps.dx, y = ps.y0 + py * ps.dy;
+                uint8_t* o = img.rgba.data() + (static_cast<size_t>(y) * w + x) * 4;
+                auto to8 = [&](uint32_t v) -> uint8_t {
+                    if (depth == 16) return static_cast<uint8_t>(v >> 8);
+                    if (depth < 8) return static_cast<uint8_t>(v * scale_small[depth]);
+                    return static_cast<uint8_t>(v);
+                };
+                if (ctype == 3) {
+                    if (s[0] * 3 + 2 >= palette.size()) bad("PNG palette index out of range");
+                    o[0] = palette[s[0] * 3]; o[1] = palette[s[0] * 3 + 1]; o[2] = palette[s[0] * 3 + 2];
+                    o[3] = s[0] < trns.size() ? trns[s[0]] : 255;
+                } else if (ctype == 0 || ctype == 4) {
+                    o[0] = o[1] = o[2] = to8(s[0]);
+                    o[3] = (ctype == 4) ? to8(s[1]) : 255;
+                    if (ctype == 0 && trns.size() >= 2 && s[0] == be16(trns.data())) o[3] = 0;
+                } else {
+                    o[0] = to8(s[0]); o[1] = to8(s[1]); o[2] = to8(s[2]);
+                    o[3] = (ctype == 6) ? to8(s[3]) : 255;
+                    if (ctype == 2 && trns.size() >= 6 && s[0] == be16(trns.data()) && s[1] == be16(trns.data() + 2) &&
+                        s[2] == be16(trns.data() + 4))
+                        o[3] = 0;
+                }
             }
         }
     }
