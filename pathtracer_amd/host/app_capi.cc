@@ -26,7 +26,7 @@ int ptapp_convert_scene(const char* in_path, const char* out_path, char* err, si
     return 0;
 }
 
-// Decodes PNG / baseline JPEG bytes.  Writes width, height and the file's channel count; when rgba is non-null and
+// Decodes PNG / JPEG bytes.  Writes width, height and the file's channel count; when rgba is non-null and
 // capacity >= width * height * 4 the pixels are copied.  0 on success, -1 on failure (message in err).
 int ptapp_decode_image(const unsigned char* bytes, size_t n, int* width, int* height, int* channels, unsigned char* rgba,
                        size_t capacity, char* err, size_t err_len) {

@@ -152,7 +152,7 @@ struct BBox {  // src/acceleration_structure.h (min/max corners)
 };
 
 // ModelLoader::loadFromFile + constructModel of the reference (src/model_loader.cc).  Reads glTF 2.0 (.glb and .gltf with
-// embedded, data-URI or external buffers and PNG / baseline JPEG images) and the flat scene container written by
+// embedded, data-URI or external buffers and PNG / JPEG images) and the flat scene container written by
 // pathtracer_amd.model.SceneModel.save (magic "PTSC0001").
 class ModelLoader {
   public:

@@ -1,9 +1,10 @@
-// image_decode.cc — PNG and baseline JPEG decoding to RGBA8 for glTF textures.
+// image_decode.cc — PNG and JPEG decoding to RGBA8 for glTF textures.
 //
 // Stands in for stbi_load_from_memory(..., 4) in the reference (src/cpu_framebuffer.cc:36-83).  PNG is lossless, so
 // the result is the reference's: 16-bit samples keep their high byte, gray is replicated, tRNS becomes alpha.  JPEG
 // decoding is defined only up to the inverse DCT and chroma upsampling a decoder chooses, so those texels can differ
-// from stb's by a few units out of 255; progressive JPEG and interlaced PNG are rejected with a clear message.
+// from stb's by a few units out of 255.  Interlaced PNG and progressive JPEG are read; arithmetic-coded, lossless and
+// 12-bit JPEG and CMYK are rejected with a clear message (stb rejects the first three too).
 #include "image_decode.h"
 
 #include <zlib.h>
@@ -48,7 +49,7 @@ DecodedImage decode_png(const uint8_t* data, size_t size) {
         }
         pos += 12ull + len;
     }
-    if (!w || !h || w > (1u << 24) || h > (1u << 24)) bad("bad PNG size");
+    if (!w || !h || w > (1u << 24) || h > (1u << 24) || static_cast<uint64_t>(w) * h > (1ull << 28)) bad("bad PNG size");
     if (interlace > 1) bad("bad PNG interlace method");
     int channels;
     switch (ctype) {
@@ -168,7 +169,7 @@ DecodedImage decode_png(const uint8_t* data, size_t size) {
     return img;
 }
 
-// ------------------------------------------------------------------------------------------------ JPEG (baseline)
+// ------------------------------------------------------------------------------------------------ JPEG
 struct Huffman {
     uint8_t size[257];
     uint16_t code[256];
@@ -273,10 +274,16 @@ void idct8x8(const float in[64], uint8_t* out, size_t stride) {
         }
 }
 
+// Baseline, extended-sequential and progressive Huffman JPEG (what stb_image, the reference's decoder, reads): every scan
+// adds to per-block coefficient arrays — whole blocks for sequential files; DC / AC bands, first passes and refinement
+// passes (successive approximation) for progressive ones; interleaved or one component per scan — and the picture is
+// reconstructed once at the end.
 DecodedImage decode_jpeg(const uint8_t* data, size_t size) {
     struct Component {
         int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
-        int bw = 0, bh = 0;  // plane size in samples (whole blocks)
+        int bw = 0, bh = 0;        // plane size in samples (whole MCUs)
+        int blocks_w = 0, blocks_h = 0;  // blocks that hold picture data (scans of this component alone cover these)
+        std::vector<int16_t> coef;  // bw/8 * bh/8 blocks of 64, natural (de-zigzagged) order
         std::vector<uint8_t> plane;
         int pred = 0;
     };
@@ -284,15 +291,15 @@ DecodedImage decode_jpeg(const uint8_t* data, size_t size) {
     Huffman dc[4], ac[4];
     bool have_dc[4] = {}, have_ac[4] = {};
     std::vector<Component> comps;
-    int width = 0, height = 0, restart = 0;
-    bool adobe_rgb = false;
+    int width = 0, height = 0, restart = 0, hmax = 1, vmax = 1, mcus_x = 0, mcus_y = 0;
+    bool adobe_rgb = false, progressive = false, any_scan = false;
     size_t pos = 2;
     while (pos + 4 <= size) {
         if (data[pos] != 0xff) { ++pos; continue; }
         const uint8_t m = data[pos + 1];
         if (m == 0xff) { ++pos; continue; }
         pos += 2;
-        if (m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
+        if (m == 0x00 || m == 0xd8 || m == 0x01 || (m >= 0xd0 && m <= 0xd7)) continue;
         if (m == 0xd9) break;
         if (pos + 2 > size) bad("truncated JPEG");
         const size_t len = be16(data + pos);
@@ -322,12 +329,15 @@ DecodedImage decode_jpeg(const uint8_t* data, size_t size) {
                 (tc ? have_ac : have_dc)[th] = true;
                 i += 17 + static_cast<size_t>(total);
             }
-        } else if (m == 0xc0 || m == 0xc1) {  // baseline / extended sequential frame
+        } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // baseline / extended sequential / progressive frame
+            if (!comps.empty()) bad("second JPEG frame header");
             if (n < 6 || s[0] != 8) bad("only 8-bit JPEG is supported");
+            progressive = (m == 0xc2);
             height = static_cast<int>(be16(s + 1));
             width = static_cast<int>(be16(s + 3));
             const int nc = s[5];
             if ((nc != 1 && nc != 3) || n < 6 + 3u * nc) bad("unsupported JPEG component count");
+            if (width <= 0 || height <= 0 || static_cast<uint64_t>(width) * height > (1ull << 28)) bad("bad JPEG size");
             comps.resize(nc);
             for (int c = 0; c < nc; ++c) {
                 comps[c].id = s[6 + 3 * c];
@@ -335,17 +345,30 @@ DecodedImage decode_jpeg(const uint8_t* data, size_t size) {
                 comps[c].v = s[7 + 3 * c] & 15;
                 comps[c].tq = s[8 + 3 * c];
                 if (comps[c].h < 1 || comps[c].h > 4 || comps[c].v < 1 || comps[c].v > 4 || comps[c].tq > 3) bad("bad JPEG frame header");
+                hmax = std::max(hmax, comps[c].h);
+                vmax = std::max(vmax, comps[c].v);
             }
-        } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-            bad("progressive, lossless and arithmetic-coded JPEG are not supported");
+            if (nc == 1) comps[0].h = comps[0].v = hmax = vmax = 1;  // a single component is never interleaved
+            mcus_x = (width + 8 * hmax - 1) / (8 * hmax);
+            mcus_y = (height + 8 * vmax - 1) / (8 * vmax);
+            for (Component& c : comps) {
+                c.bw = mcus_x * c.h * 8;
+                c.bh = mcus_y * c.v * 8;
+                c.blocks_w = ((width * c.h + hmax - 1) / hmax + 7) / 8;
+                c.blocks_h = ((height * c.v + vmax - 1) / vmax + 7) / 8;
+                c.coef.assign(static_cast<size_t>(c.bw) * c.bh, 0);
+            }
+        } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+            bad("lossless, hierarchical and arithmetic-coded JPEG are not supported");
         } else if (m == 0xdd) {
             if (n >= 2) restart = static_cast<int>(be16(s));
         } else if (m == 0xee) {
             if (n >= 12 && !std::memcmp(s, "Adobe", 5)) adobe_rgb = (s[11] == 0);
-        } else if (m == 0xda) {  // start of scan: baseline files hold all components in one scan
-            if (comps.empty() || width <= 0 || height <= 0) bad("JPEG scan before frame header");
-            const int ns = s[0];
-            if (ns != static_cast<int>(comps.size()) || n < 1 + 2u * ns + 3) bad("multi-scan JPEG is not supported");
+        } else if (m == 0xda) {  // one scan
+            if (comps.empty()) bad("JPEG scan before frame header");
+            const int ns = n ? s[0] : 0;
+            if (ns < 1 || ns > static_cast<int>(comps.size()) || n < 1 + 2u * ns + 3) bad("bad JPEG scan header");
+            Component* in_scan[3] = {nullptr, nullptr, nullptr};
             for (int k = 0; k < ns; ++k) {
                 const int id = s[1 + 2 * k];
                 Component* c = nullptr;
@@ -353,100 +376,202 @@ DecodedImage decode_jpeg(const uint8_t* data, size_t size) {
                 if (!c) bad("bad JPEG scan header");
                 c->td = s[2 + 2 * k] >> 4;
                 c->ta = s[2 + 2 * k] & 15;
-                if (c->td > 3 || c->ta > 3 || !have_dc[c->td] || !have_ac[c->ta]) bad("JPEG scan names a missing Huffman table");
+                if (c->td > 3 || c->ta > 3) bad("bad JPEG scan header");
+                in_scan[k] = c;
             }
-            int hmax = 1, vmax = 1;
-            for (const Component& c : comps) { hmax = std::max(hmax, c.h); vmax = std::max(vmax, c.v); }
-            const int mcu_w = 8 * hmax, mcu_h = 8 * vmax;
-            const int mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-            for (Component& c : comps) {
-                c.bw = mcus_x * c.h * 8;
-                c.bh = mcus_y * c.v * 8;
-                c.plane.assign(static_cast<size_t>(c.bw) * c.bh, 0);
-                c.pred = 0;
+            const int ss = s[1 + 2 * ns], se = s[2 + 2 * ns], ah = s[3 + 2 * ns] >> 4, al = s[3 + 2 * ns] & 15;
+            if (progressive) {
+                if (ss > se || se > 63 || ah > 13 || al > 13 || (ss == 0 && se != 0) || (ss > 0 && ns != 1)) bad("bad JPEG progressive scan");
+            } else if (ss != 0 || se != 63 || ah != 0 || al != 0) {
+                bad("bad JPEG sequential scan");
             }
+            for (int k = 0; k < ns; ++k) {
+                const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss > 0;
+                if ((need_dc && !have_dc[in_scan[k]->td]) || (need_ac && !have_ac[in_scan[k]->ta])) bad("JPEG scan names a missing Huffman table");
+                in_scan[k]->pred = 0;
+            }
+            any_scan = true;
             BitReader br{data + pos + len, data + size};
-            int until_restart = restart;
-            float block[64];
-            for (int my = 0; my < mcus_y; ++my)
-                for (int mx = 0; mx < mcus_x; ++mx) {
-                    if (restart && until_restart == 0) {
-                        // byte-align, skip the RSTn marker, reset predictors
-                        br.reset();
-                        const uint8_t* q = br.p;
-                        while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) ++q;
-                        br.p = (q + 2 <= br.end) ? q + 2 : br.end;
-                        for (Component& c : comps) c.pred = 0;
-                        until_restart = restart;
+            int eobrun = 0;
+            auto block_at = [](Component& c, int bx, int by) { return c.coef.data() + (static_cast<size_t>(by) * (c.bw / 8) + bx) * 64; };
+            auto decode_block = [&](Component& c, int16_t* q) {
+                if (!progressive) {
+                    const int t = br.decode(dc[c.td]);
+                    if (t > 11) bad("bad JPEG DC size");
+                    c.pred += extend_sign(br.get(t), t);
+                    q[0] = static_cast<int16_t>(c.pred);
+                    for (int k = 1; k < 64;) {
+                        const int rs = br.decode(ac[c.ta]);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r != 15) break;  // end of block
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > 63) bad("bad JPEG AC run");
+                        q[kZigzag[k]] = static_cast<int16_t>(extend_sign(br.get(sz), sz));
+                        ++k;
                     }
-                    for (Component& c : comps)
-                        for (int by = 0; by < c.v; ++by)
-                            for (int bx = 0; bx < c.h; ++bx) {
-                                std::fill(block, block + 64, 0.0f);
-                                const int t = br.decode(dc[c.td]);
-                                if (t > 11) bad("bad JPEG DC size");
-                                c.pred += extend_sign(br.get(t), t);
-                                block[0] = static_cast<float>(c.pred * quant[c.tq][0]);
-                                for (int k = 1; k < 64;) {
-                                    const int rs = br.decode(ac[c.ta]);
-                                    const int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r != 15) break;  // end of block
-                                        k += 16;
-                                        continue;
-                                    }
-                                    k += r;
-                                    if (k > 63) bad("bad JPEG AC run");
-                                    const int z = kZigzag[k];
-                                    block[z] = static_cast<float>(extend_sign(br.get(sz), sz) * quant[c.tq][z]);
-                                    ++k;
-                                }
-                                uint8_t* dst = c.plane.data() + static_cast<size_t>((my * c.v + by) * 8) * c.bw + (mx * c.h + bx) * 8;
-                                idct8x8(block, dst, static_cast<size_t>(c.bw));
+                } else if (ss == 0) {
+                    if (ah == 0) {  // DC, first pass: the value without its low `al` bits
+                        const int t = br.decode(dc[c.td]);
+                        if (t > 11) bad("bad JPEG DC size");
+                        c.pred += extend_sign(br.get(t), t);
+                        q[0] = static_cast<int16_t>(c.pred * (1 << al));
+                    } else if (br.get(1)) {  // DC, refinement: one more bit
+                        q[0] = static_cast<int16_t>(q[0] | (1 << al));
+                    }
+                } else if (ah == 0) {  // AC band, first pass
+                    if (eobrun > 0) { --eobrun; return; }
+                    for (int k = ss; k <= se;) {
+                        const int rs = br.decode(ac[c.ta]);
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r < 15) {  // end of band for this and the next eobrun blocks
+                                eobrun = (1 << r) - 1;
+                                if (r) eobrun += br.get(r);
+                                break;
                             }
-                    if (restart) --until_restart;
-                }
-            // planes -> RGBA: chroma by bilinear interpolation between sample centres
-            DecodedImage img;
-            img.width = width;
-            img.height = height;
-            img.channels = static_cast<int>(comps.size());
-            img.rgba.resize(static_cast<size_t>(width) * height * 4);
-            auto sample = [&](const Component& c, int x, int y) -> float {
-                if (c.h == hmax && c.v == vmax) return c.plane[static_cast<size_t>(y) * c.bw + x];
-                const float fx = (x + 0.5f) * c.h / hmax - 0.5f, fy = (y + 0.5f) * c.v / vmax - 0.5f;
-                const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;
-                const int x0 = static_cast<int>(std::floor(fx)), y0 = static_cast<int>(std::floor(fy));
-                const float tx = fx - x0, ty = fy - y0;
-                auto at = [&](int xx, int yy) {
-                    xx = std::clamp(xx, 0, cw - 1);
-                    yy = std::clamp(yy, 0, ch - 1);
-                    return static_cast<float>(c.plane[static_cast<size_t>(yy) * c.bw + xx]);
-                };
-                const float top = at(x0, y0) * (1 - tx) + at(x0 + 1, y0) * tx, bot = at(x0, y0 + 1) * (1 - tx) + at(x0 + 1, y0 + 1) * tx;
-                return top * (1 - ty) + bot * ty;
-            };
-            auto to8 = [](float v) { return static_cast<uint8_t>(std::clamp(static_cast<int>(std::lround(v)), 0, 255)); };
-            for (int y = 0; y < height; ++y)
-                for (int x = 0; x < width; ++x) {
-                    uint8_t* o = img.rgba.data() + (static_cast<size_t>(y) * width + x) * 4;
-                    if (comps.size() == 1) {
-                        o[0] = o[1] = o[2] = to8(sample(comps[0], x, y));
-                    } else if (adobe_rgb) {
-                        o[0] = to8(sample(comps[0], x, y)); o[1] = to8(sample(comps[1], x, y)); o[2] = to8(sample(comps[2], x, y));
-                    } else {
-                        const float Y = sample(comps[0], x, y), cb = sample(comps[1], x, y) - 128.0f, cr = sample(comps[2], x, y) - 128.0f;
-                        o[0] = to8(Y + 1.402f * cr);
-                        o[1] = to8(Y - 0.344136f * cb - 0.714136f * cr);
-                        o[2] = to8(Y + 1.772f * cb);
+                            k += 16;
+                            continue;
+                        }
+                        k += r;
+                        if (k > se) bad("bad JPEG AC run");
+                        q[kZigzag[k]] = static_cast<int16_t>(extend_sign(br.get(sz), sz) * (1 << al));
+                        ++k;
                     }
-                    o[3] = 255;
+                } else {  // AC band, refinement: correction bits for coefficients already non-zero, new ones of magnitude 1 << al
+                    const int p1 = 1 << al, m1 = -(1 << al);
+                    auto refine = [&](int16_t& v) {
+                        if (br.get(1) && (v & p1) == 0) v = static_cast<int16_t>(v + (v >= 0 ? p1 : m1));
+                    };
+                    int k = ss;
+                    if (eobrun == 0) {
+                        for (; k <= se; ++k) {
+                            const int rs = br.decode(ac[c.ta]);
+                            int r = rs >> 4;
+                            const int sz = rs & 15;
+                            int value = 0;
+                            if (sz == 0) {
+                                if (r < 15) {
+                                    eobrun = 1 << r;
+                                    if (r) eobrun += br.get(r);
+                                    break;
+                                }
+                            } else {
+                                if (sz != 1) bad("bad JPEG refinement code");
+                                value = br.get(1) ? p1 : m1;
+                            }
+                            for (; k <= se; ++k) {  // pass r still-zero coefficients, refining the non-zero ones on the way
+                                int16_t& v = q[kZigzag[k]];
+                                if (v != 0) {
+                                    refine(v);
+                                } else {
+                                    if (r == 0) {
+                                        if (value) v = static_cast<int16_t>(value);
+                                        break;
+                                    }
+                                    --r;
+                                }
+                            }
+                        }
+                    }
+                    if (eobrun > 0) {
+                        for (; k <= se; ++k) {
+                            int16_t& v = q[kZigzag[k]];
+                            if (v != 0) refine(v);
+                        }
+                        --eobrun;
+                    }
                 }
-            return img;
+            };
+            int until_restart = restart;
+            auto maybe_restart = [&]() {
+                if (!restart) return;
+                if (until_restart == 0) {  // byte-align, skip the RSTn marker, reset the predictors and the band run
+                    br.reset();
+                    const uint8_t* q = br.p;
+                    while (q + 1 < br.end && !(q[0] == 0xff && q[1] >= 0xd0 && q[1] <= 0xd7)) ++q;
+                    br.p = (q + 2 <= br.end) ? q + 2 : br.end;
+                    for (Component& c : comps) c.pred = 0;
+                    eobrun = 0;
+                    until_restart = restart;
+                }
+                --until_restart;
+            };
+            if (ns == 1) {  // one component: its blocks row by row, only those that hold picture data
+                Component& c = *in_scan[0];
+                for (int by = 0; by < c.blocks_h; ++by)
+                    for (int bx = 0; bx < c.blocks_w; ++bx) {
+                        maybe_restart();
+                        decode_block(c, block_at(c, bx, by));
+                    }
+            } else {
+                for (int my = 0; my < mcus_y; ++my)
+                    for (int mx = 0; mx < mcus_x; ++mx) {
+                        maybe_restart();
+                        for (int k = 0; k < ns; ++k) {
+                            Component& c = *in_scan[k];
+                            for (int by = 0; by < c.v; ++by)
+                                for (int bx = 0; bx < c.h; ++bx) decode_block(c, block_at(c, mx * c.h + bx, my * c.v + by));
+                        }
+                    }
+            }
+            pos = static_cast<size_t>(br.p - data);  // at the marker that ended the scan (or wherever the data ran out)
+            continue;
         }
         pos += len;
     }
-    bad("JPEG without image data");
+    if (!any_scan) bad("JPEG without image data");
+    // coefficients -> samples
+    float block[64];
+    for (Component& c : comps) {
+        c.plane.assign(static_cast<size_t>(c.bw) * c.bh, 0);
+        for (int by = 0; by < c.bh / 8; ++by)
+            for (int bx = 0; bx < c.bw / 8; ++bx) {
+                const int16_t* q = c.coef.data() + (static_cast<size_t>(by) * (c.bw / 8) + bx) * 64;
+                for (int k = 0; k < 64; ++k) block[k] = static_cast<float>(q[k] * static_cast<int>(quant[c.tq][k]));
+                idct8x8(block, c.plane.data() + static_cast<size_t>(by * 8) * c.bw + bx * 8, static_cast<size_t>(c.bw));
+            }
+    }
+    // planes -> RGBA: chroma by bilinear interpolation between sample centres
+    DecodedImage img;
+    img.width = width;
+    img.height = height;
+    img.channels = static_cast<int>(comps.size());
+    img.rgba.resize(static_cast<size_t>(width) * height * 4);
+    auto sample = [&](const Component& c, int x, int y) -> float {
+        if (c.h == hmax && c.v == vmax) return c.plane[static_cast<size_t>(y) * c.bw + x];
+        const float fx = (x + 0.5f) * c.h / hmax - 0.5f, fy = (y + 0.5f) * c.v / vmax - 0.5f;
+        const int cw = (width * c.h + hmax - 1) / hmax, ch = (height * c.v + vmax - 1) / vmax;
+        const int x0 = static_cast<int>(std::floor(fx)), y0 = static_cast<int>(std::floor(fy));
+        const float tx = fx - x0, ty = fy - y0;
+        auto at = [&](int xx, int yy) {
+            xx = std::clamp(xx, 0, cw - 1);
+            yy = std::clamp(yy, 0, ch - 1);
+            return static_cast<float>(c.plane[static_cast<size_t>(yy) * c.bw + xx]);
+        };
+        const float top = at(x0, y0) * (1 - tx) + at(x0 + 1, y0) * tx, bot = at(x0, y0 + 1) * (1 - tx) + at(x0 + 1, y0 + 1) * tx;
+        return top * (1 - ty) + bot * ty;
+    };
+    auto to8 = [](float v) { return static_cast<uint8_t>(std::clamp(static_cast<int>(std::lround(v)), 0, 255)); };
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            uint8_t* o = img.rgba.data() + (static_cast<size_t>(y) * width + x) * 4;
+            if (comps.size() == 1) {
+                o[0] = o[1] = o[2] = to8(sample(comps[0], x, y));
+            } else if (adobe_rgb) {
+                o[0] = to8(sample(comps[0], x, y)); o[1] = to8(sample(comps[1], x, y)); o[2] = to8(sample(comps[2], x, y));
+            } else {
+                const float Y = sample(comps[0], x, y), cb = sample(comps[1], x, y) - 128.0f, cr = sample(comps[2], x, y) - 128.0f;
+                o[0] = to8(Y + 1.402f * cr);
+                o[1] = to8(Y - 0.344136f * cb - 0.714136f * cr);
+                o[2] = to8(Y + 1.772f * cb);
+            }
+            o[3] = 255;
+        }
+    return img;
 }
 
 }  // namespace

@@ -1,4 +1,4 @@
-// image_decode.h — PNG / baseline JPEG bytes to RGBA8 (what stbi_load_from_memory(..., 4) gives the reference).
+// image_decode.h — PNG / JPEG bytes to RGBA8 (what stbi_load_from_memory(..., 4) gives the reference).
 #pragma once
 
 #include <cstddef>

@@ -84,9 +84,34 @@ def test_baseline_jpeg_decoding_close_to_pillow(lib):
     got, ch = decode(lib, gray)
     ref = np.asarray(PIL.open(io.BytesIO(gray)).convert("RGBA")).astype(np.int32)
     assert ch == 1 and np.abs(got.astype(np.int32) - ref).max() <= 2
-    prog = encoded(PIL.fromarray(smooth, "RGB"), "JPEG", progressive=True)
-    with pytest.raises(RuntimeError, match="progressive"):
-        decode(lib, prog)
+
+
+def test_progressive_jpeg_equals_its_sequential_twin(lib):
+    """Progressive files (spectral selection + successive approximation, DC and AC refinement scans; what stb_image, the
+    reference's decoder, reads too) carry the same quantised coefficients as a sequential file made from the same picture
+    with the same tables, so both must decode to EXACTLY the same pixels here; and stay close to Pillow's decoder.
+    Sizes that are not multiples of the MCU make the single-component scans cover fewer blocks than the interleaved
+    ones; noise exercises long runs, refinement of many coefficients and end-of-band runs."""
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:61, 0:83]
+    smooth = np.clip(np.stack([127 + 100 * np.sin(x / 9.0), 127 + 90 * np.cos(y / 7.0), 60 + (x + y) * 1.1], -1), 0, 255)
+    noisy = np.clip(smooth + rng.normal(scale=40.0, size=smooth.shape), 0, 255).astype(np.uint8)
+    for img, quality in ((smooth.astype(np.uint8), 90), (noisy, 95), (noisy, 35)):
+        for sub in (0, 1, 2):
+            for kw in ({}, {"restart_marker_blocks": 2}):
+                seq = encoded(PIL.fromarray(img, "RGB"), "JPEG", quality=quality, subsampling=sub, **kw)
+                prog = encoded(PIL.fromarray(img, "RGB"), "JPEG", quality=quality, subsampling=sub, progressive=True, **kw)
+                assert b"\xff\xc2" in prog and b"\xff\xc2" not in seq
+                a, ch = decode(lib, prog)
+                b, _ = decode(lib, seq)
+                assert ch == 3 and np.array_equal(a, b), (quality, sub, kw, np.abs(a.astype(int) - b).max())
+                ref = np.asarray(PIL.open(io.BytesIO(prog)).convert("RGBA")).astype(np.int32)
+                d = np.abs(a.astype(np.int32) - ref)
+                assert d.mean() < 1.5, (quality, sub, d.max(), d.mean())
+    gray = encoded(PIL.fromarray(noisy[..., 0], "L"), "JPEG", quality=85, progressive=True)
+    got, ch = decode(lib, gray)
+    ref = np.asarray(PIL.open(io.BytesIO(gray)).convert("RGBA")).astype(np.int32)
+    assert ch == 1 and np.abs(got.astype(np.int32) - ref).max() <= 2
 
 
 def convert(lib, src, dst):
