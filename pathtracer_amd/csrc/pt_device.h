@@ -112,6 +112,8 @@ struct SceneDev {
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)
     uint32_t n_instances;
     uint32_t n_top_nodes;         // nodes[0 .. n_top_nodes) are the most visited ones (kept in LDS by the traversal kernel)
+    const DevNode* tlas;          // tree over the instances' boxes (child references: leaf bit | instance), or null: few
+                                  // instances, every ray tests them all
     const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
     uint32_t n_top_nodes4;        // likewise for nodes4
     int32_t env_w, env_h;

@@ -39,6 +39,8 @@ struct HitQueue {
 #define PT_CAND_MAX 8
 #endif
 constexpr int kCandMax = PT_CAND_MAX;
+constexpr uint32_t kTlasLinearMax = 32;  // up to this many instances every ray tests every bound; above, a tree over the bounds culls
+constexpr int kTlasStack = 40;          // depth of that tree's traversal stack (the host builder keeps the tree shallower)
 struct CandQueue {
     uint2* e;
     uint32_t stride;

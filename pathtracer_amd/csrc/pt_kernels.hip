@@ -447,6 +447,97 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
 }
 
+// The same pass for scenes with many instances.  The reference tests every object's bound for every ray
+// (acceleration_structure.cc:599-607), which is what tlas_kernel does while that is cheap; here a binary tree over the
+// bounds' axis-aligned boxes (the first three slabs of a 14-DOP are its box) culls first, and only the instances whose
+// box the ray enters get the 7-slab test.  A box test uses the arithmetic of those three slabs, which is monotonic in the
+// plane positions: a ray that enters an instance's box enters every box around it, so no candidate is lost.  The
+// candidates come in tree order here, so the insertion orders by (distance, table index) explicitly.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                           const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                                           TraceCounters* counters) {
+    __shared__ uint32_t s_stack[kTlasStack][kBlock];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t gid = blockIdx.x * kBlock + tid;
+    if (gid >= n) return;
+    const float4 ro = ray_o[gid], rd = ray_d[gid];
+    const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
+    const DopRay pr = dop_projections(ld3(ro), ld3(rd));
+    const bool finite3 = (fabsf(pr.ip[0]) < kInfF) && (fabsf(pr.ip[1]) < kInfF) && (fabsf(pr.ip[2]) < kInfF);
+    float key[kCandMax];
+    uint32_t slot[kCandMax];
+#pragma unroll
+    for (int j = 0; j < kCandMax; ++j) { key[j] = kInfF; slot[j] = PT_NO_NODE; }
+    auto enters = [&](const float* lo, const float* hi) {
+        if (!finite3) return true;  // (a zero direction component can make a slab NaN: such rays skip the culling)
+        float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float t0 = (lo[a] - pr.op[a]) * pr.ip[a], t1 = (hi[a] - pr.op[a]) * pr.ip[a];
+            tmin = __builtin_fmaxf(tmin, __builtin_fminf(t0, t1));
+            tmax = __builtin_fminf(tmax, __builtin_fmaxf(t0, t1));
+        }
+        return (tmin <= tmax) && (tmax > 0.0f);
+    };
+    uint32_t tested = 0;
+    int sp = 0;
+    uint32_t cur = 0;  // node 0 is the root
+    for (;;) {
+        if (cur & PT_LEAF_BIT) {
+            const uint32_t k = cur & ~PT_LEAF_BIT;
+            ++tested;
+            // (the per-lane form: no wave-level early out, the lanes are at different instances)
+            const float* dop = sc.instances[k].dop;
+            float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
+            bool hit = true;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                float t0 = (dop[2 * i] - pr.op[i]) * pr.ip[i];
+                float t1 = (dop[2 * i + 1] - pr.op[i]) * pr.ip[i];
+                if (t0 > t1) { float s = t0; t0 = t1; t1 = s; }
+                tmin = (tmin < t0) ? t0 : tmin;
+                tmax = (t1 < tmax) ? t1 : tmax;
+                if (hit && (tmax < tmin)) hit = false;
+            }
+            const float dist = forward_distance(hit, tmin, tmax);
+            if (dist < kInfF) {
+                float ck = any_hit ? -static_cast<float>(k) : dist;
+                uint32_t cs = k;
+#pragma unroll
+                for (int j = 0; j < kCandMax; ++j) {
+                    const bool sw = (slot[j] == PT_NO_NODE) || (ck < key[j]) || (ck == key[j] && cs < slot[j]);
+                    const float tk = key[j];
+                    const uint32_t ts = slot[j];
+                    key[j] = sw ? ck : tk;
+                    slot[j] = sw ? cs : ts;
+                    ck = sw ? tk : ck;
+                    cs = sw ? ts : cs;
+                }
+            }
+            if (sp == 0) break;
+            cur = s_stack[--sp][tid];
+        } else {
+            const DevNode& nd = sc.tlas[cur];
+            const bool l = enters(nd.l_lo, nd.l_hi), r = enters(nd.r_lo, nd.r_hi);
+            if (l && r) {
+                if (sp < kTlasStack) s_stack[sp++][tid] = nd.right;
+                cur = nd.left;
+            } else if (l || r) {
+                cur = l ? nd.left : nd.right;
+            } else {
+                if (sp == 0) break;
+                cur = s_stack[--sp][tid];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kCandMax; ++j)
+        if (j == 0 || slot[j - 1] != PT_NO_NODE)
+            cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j]);
+    if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(tested));
+}
+
 // Continuation of the visiting order for rays that consumed kCandMax candidates: rescan all DOPs.
 __device__ __noinline__ uint2 tlas_rescan(const SceneDev& sc, f3 ow, f3 dw, bool any_hit, float last_key, uint32_t last_slot) {
     const DopRay pr = dop_projections(ow, dw);
@@ -1644,7 +1735,8 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
     (void)hipMemsetAsync(overflow, 0, sizeof(uint32_t), st);
     const dim3 g_all(blocks_for(n)), g_p(grid), g_c(std::min<uint32_t>(n_blocks, 64u)), b(kBlock);
     if (counters) {
-        hipLaunchKernelGGL(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (sc.tlas) hipLaunchKernelGGL(tlas_tree_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        else hipLaunchKernelGGL(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         if (sc.nodes4)
             hipLaunchKernelGGL((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
@@ -1655,7 +1747,8 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         hipLaunchKernelGGL(extend_overflow_kernel<true>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
                            spill_depth, stride, counters);
     } else {
-        hipLaunchKernelGGL(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (sc.tlas) hipLaunchKernelGGL(tlas_tree_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        else hipLaunchKernelGGL(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         if (sc.nodes4)
             hipLaunchKernelGGL((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,

@@ -418,6 +418,28 @@ def random_soup(seed: int, n_objects: int = 5, tris_per_object: int = 4000, offs
     return b.build()
 
 
+def many_objects(n_objects: int = 400, seed: int = 9) -> SceneModel:
+    """``n_objects`` small objects (instances of four meshes: blob, torus, box, sphere) scattered over a floor, each under
+    its own rotation and scale: the case in which testing every object's bound for every ray is what costs."""
+    rng = np.random.default_rng(seed)
+    b = ModelBuilder("many_objects")
+    floor_mat = b.add_material(base_color=(0.7, 0.7, 0.72, 1), metallic=0.0, roughness=0.8)
+    side = 0.6 * np.sqrt(n_objects)
+    b.add_object(b.add_mesh(*_args(plane(8, 8, 2.2 * side, 2.2 * side)), material=floor_mat), np.eye(4))
+    meshes = []
+    for k, shape in enumerate((blob(10, 20, 0.25), torus(16, 8, 0.22, 0.08), box(0.3, 0.3, 0.3), uv_sphere(8, 16, 0.2))):
+        mat = b.add_material(base_color=(0.3 + 0.2 * k, 0.8 - 0.15 * k, 0.4 + 0.1 * k, 1), metallic=float(k % 2), roughness=0.3 + 0.15 * k)
+        meshes.append(b.add_mesh(*_args(shape), material=mat))
+    for i in range(n_objects):
+        m = np.eye(4)
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        m[:3, :3] = q * rng.uniform(0.6, 1.5)
+        m[:3, 3] = (rng.uniform(-side, side), rng.uniform(0.3, 1.6), rng.uniform(-side, side))
+        b.add_object(meshes[i % len(meshes)], m)
+    b.add_camera(Camera((0.0, 0.9 * side, 2.0 * side), (0.0, -0.45, -1.0), (0.0, 1.0, 0.0), np.radians(50.0), 0.1, 1000.0))
+    return b.build()
+
+
 def tiny_scene(seed: int = 3) -> SceneModel:
     """A few hundred triangles exercising every material feature; small enough for the CPU oracle in tests."""
     return readme_standin(detail=0.03, seed=seed)

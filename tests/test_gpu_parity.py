@@ -301,6 +301,54 @@ def test_random_soups_both_node_layouts(seed, offset, flat):
         del g
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_many_objects_instance_tree(wide):
+    """Hundreds of instances: the instance pass culls with a tree over the bounds' boxes instead of testing every bound
+    for every ray.  The candidate lists must be the ones the full scan makes: with binary nodes everything equals the
+    oracle (hit records of camera rays and of random closest / any-hit rays bit for bit, ray counts, instances entered,
+    frames within the summation tolerance) — and equals this library's own full scan (PTGPU_TLAS=linear)."""
+    model, env = scenes.many_objects(300), scenes.synthetic_env()
+    w, h = 192, 108
+    st = H.settings(program=2, spp=2, bounces=3, wide=wide)
+    g = H.make_gpu(model, env, st, w, h)
+    o = H.make_oracle(model, env, H.settings(program=2, spp=2, bounces=3), w, h)
+    exact, _ = H.hits_equal(o.render_hits(w, h), g.render_hits(w, h))
+    assert exact.all() if not wide else exact.mean() >= 0.9999
+    img_o, so = o.render_frame(w, h)
+    img_g, sg = g.render_counted(w, h)
+    bad = (np.abs(img_g[..., :3] - img_o[..., :3]) > 2e-5 * np.maximum(1.0, np.abs(img_o[..., :3]))).any(axis=-1)
+    if not wide:
+        assert sg.rays == so.rays and sg.instances_entered == so.instances_entered and not bad.any()
+        assert sg.nodes_visited == so.nodes_visited and sg.triangles_tested == so.triangles_tested
+    else:
+        assert abs(int(sg.rays) - int(so.rays)) <= 1e-5 * so.rays and bad.mean() <= 1e-4
+    assert sg.instances_tested < 0.2 * so.instances_tested          # the tree culls most of the 301 bound tests per ray
+    rng = np.random.default_rng(21)
+    n = 20000
+    org = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+    org[:, 1] = rng.uniform(0.05, 3.0, n)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:1500] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 1500)] * rng.choice([-1.0, 1.0], (1500, 1)).astype(np.float32)
+    flags = (rng.uniform(size=n) < 0.5).astype(np.uint8)
+    ref = o.intersect_rays(org, d, flags)
+    got = g.intersect_rays(org, d, flags)
+    exact, _ = H.hits_equal(ref, got)
+    if not wide:
+        assert exact.all(), int((~exact).sum())
+    else:
+        assert (got["hit"] == ref["hit"]).mean() >= 0.9999 and exact[flags == 0].mean() >= 0.9999
+    os.environ["PTGPU_TLAS"] = "linear"
+    try:
+        lin = H.make_gpu(model, env, st, w, h)
+    finally:
+        del os.environ["PTGPU_TLAS"]
+    exact, _ = H.hits_equal(lin.intersect_rays(org, d, flags), got)
+    assert exact.all()
+    _, sl = lin.render_counted(w, h)
+    assert sl.rays == sg.rays and sl.instances_tested == so.instances_tested
+
+
 def test_golden_converged_images(tiny, golden):
     model, env = tiny
     w, h = 64, 36
