@@ -65,6 +65,15 @@ struct alignas(16) DevInstance {  // 64 B
     uint32_t object_index;
     uint32_t mesh_index;
 };
+// Node of the tree over the instances' boxes, stored in depth-first order and threaded: a ray that enters the box goes on
+// to the next node (an inner node's first child follows it), a ray that does not goes to `skip` (the node after the
+// subtree) — no stack.  A leaf (inst != PT_NO_NODE) names one instance.
+struct alignas(16) TlasNode {     // 32 B
+    float lo[3];
+    uint32_t skip;
+    float hi[3];
+    uint32_t inst;
+};
 struct alignas(16) DevXform {     // 128 B
     float inv[12];                // inverse model matrix columns c0..c3, xyz rows
     float model[12];              // model matrix columns c0..c3, xyz rows
@@ -112,8 +121,8 @@ struct SceneDev {
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)
     uint32_t n_instances;
     uint32_t n_top_nodes;         // nodes[0 .. n_top_nodes) are the most visited ones (kept in LDS by the traversal kernel)
-    const DevNode* tlas;          // tree over the instances' boxes (child references: leaf bit | instance), or null: few
-                                  // instances, every ray tests them all
+    const TlasNode* tlas;         // threaded tree over the instances' boxes, or null: few instances, every ray tests them all
+    uint32_t n_tlas;              // its node count
     const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
     uint32_t n_top_nodes4;        // likewise for nodes4
     int32_t env_w, env_h;

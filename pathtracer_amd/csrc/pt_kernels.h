@@ -39,8 +39,11 @@ struct HitQueue {
 #define PT_CAND_MAX 8
 #endif
 constexpr int kCandMax = PT_CAND_MAX;
-constexpr uint32_t kTlasLinearMax = 32;  // up to this many instances every ray tests every bound; above, a tree over the bounds culls
-constexpr int kTlasStack = 40;          // depth of that tree's traversal stack (the host builder keeps the tree shallower)
+#ifndef PT_TLAS_LINEAR_MAX
+#define PT_TLAS_LINEAR_MAX 96
+#endif
+constexpr uint32_t kTlasLinearMax = PT_TLAS_LINEAR_MAX;  // up to this many instances every ray tests every bound; above, a tree over the bounds culls
+constexpr uint32_t kTlasLds = 512;       // nodes of that tree kept in LDS by the instance pass (16 KB)
 struct CandQueue {
     uint2* e;
     uint32_t stride;

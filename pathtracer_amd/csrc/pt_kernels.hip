@@ -450,16 +450,21 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
 // The same pass for scenes with many instances.  The reference tests every object's bound for every ray
 // (acceleration_structure.cc:599-607), which is what tlas_kernel does while that is cheap; here a binary tree over the
 // bounds' axis-aligned boxes (the first three slabs of a 14-DOP are its box) culls first, and only the instances whose
-// box the ray enters get the 7-slab test.  A box test uses the arithmetic of those three slabs, which is monotonic in the
+// box the ray enters get the 7-slab test.  The tree is stored depth first and threaded (TlasNode), so a ray walks it
+// without a stack, in one fixed order.  A box test uses the arithmetic of those three slabs, which is monotonic in the
 // plane positions: a ray that enters an instance's box enters every box around it, so no candidate is lost.  The
 // candidates come in tree order here, so the insertion orders by (distance, table index) explicitly.
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                            const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                            TraceCounters* counters) {
-    __shared__ uint32_t s_stack[kTlasStack][kBlock];
+    __shared__ float4 s_nodes[kTlasLds * 2];  // the first nodes of the tree (depth-first order: its top and its left flank)
     const uint32_t tid = threadIdx.x;
     const uint32_t gid = blockIdx.x * kBlock + tid;
+    const uint32_t n_nodes = sc.n_tlas;
+    const uint32_t n_lds = n_nodes < kTlasLds ? n_nodes : kTlasLds;
+    for (uint32_t i = tid; i < n_lds * 2u; i += kBlock) s_nodes[i] = reinterpret_cast<const float4*>(sc.tlas)[i];
+    __syncthreads();
     if (gid >= n) return;
     const float4 ro = ray_o[gid], rd = ray_d[gid];
     const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
@@ -469,65 +474,57 @@ __global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const fl
     uint32_t slot[kCandMax];
 #pragma unroll
     for (int j = 0; j < kCandMax; ++j) { key[j] = kInfF; slot[j] = PT_NO_NODE; }
-    auto enters = [&](const float* lo, const float* hi) {
-        if (!finite3) return true;  // (a zero direction component can make a slab NaN: such rays skip the culling)
-        float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float t0 = (lo[a] - pr.op[a]) * pr.ip[a], t1 = (hi[a] - pr.op[a]) * pr.ip[a];
-            tmin = __builtin_fmaxf(tmin, __builtin_fminf(t0, t1));
-            tmax = __builtin_fminf(tmax, __builtin_fmaxf(t0, t1));
-        }
-        return (tmin <= tmax) && (tmax > 0.0f);
-    };
     uint32_t tested = 0;
-    int sp = 0;
-    uint32_t cur = 0;  // node 0 is the root
-    for (;;) {
-        if (cur & PT_LEAF_BIT) {
-            const uint32_t k = cur & ~PT_LEAF_BIT;
-            ++tested;
-            // (the per-lane form: no wave-level early out, the lanes are at different instances)
-            const float* dop = sc.instances[k].dop;
-            float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
-            bool hit = true;
+    for (uint32_t i = 0; i < n_nodes;) {
+        const float4* np = (i < n_lds) ? s_nodes + i * 2u : reinterpret_cast<const float4*>(sc.tlas + i);
+        const float4 a = np[0], b = np[1];  // lo.xyz skip | hi.xyz inst
+        bool inside = true;
+        if (finite3) {  // (a zero direction component can make a slab NaN: such rays skip the culling)
+            const float t0x = (a.x - pr.op[0]) * pr.ip[0], t1x = (b.x - pr.op[0]) * pr.ip[0];
+            const float t0y = (a.y - pr.op[1]) * pr.ip[1], t1y = (b.y - pr.op[1]) * pr.ip[1];
+            const float t0z = (a.z - pr.op[2]) * pr.ip[2], t1z = (b.z - pr.op[2]) * pr.ip[2];
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+            const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+            inside = (tmin <= tmax) && (tmax > 0.0f);
+        }
+        const uint32_t skip = __float_as_uint(a.w), inst = __float_as_uint(b.w);
+        if (!inside) {
+            i = skip;
+            continue;
+        }
+        if (inst == PT_NO_NODE) {
+            ++i;  // an inner node: its first child is the next node
+            continue;
+        }
+        i = skip;
+        const uint32_t k = inst;
+        ++tested;
+        // (the per-lane form of the 7-slab test: no wave-level early out, the lanes are at different instances)
+        const float* dop = sc.instances[k].dop;
+        float tmin = -3.402823466e+38f, tmax = 3.402823466e+38f;
+        bool hit = true;
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                float t0 = (dop[2 * i] - pr.op[i]) * pr.ip[i];
-                float t1 = (dop[2 * i + 1] - pr.op[i]) * pr.ip[i];
-                if (t0 > t1) { float s = t0; t0 = t1; t1 = s; }
-                tmin = (tmin < t0) ? t0 : tmin;
-                tmax = (t1 < tmax) ? t1 : tmax;
-                if (hit && (tmax < tmin)) hit = false;
-            }
-            const float dist = forward_distance(hit, tmin, tmax);
-            if (dist < kInfF) {
-                float ck = any_hit ? -static_cast<float>(k) : dist;
-                uint32_t cs = k;
+        for (int s7 = 0; s7 < 7; ++s7) {
+            float t0 = (dop[2 * s7] - pr.op[s7]) * pr.ip[s7];
+            float t1 = (dop[2 * s7 + 1] - pr.op[s7]) * pr.ip[s7];
+            if (t0 > t1) { float sw = t0; t0 = t1; t1 = sw; }
+            tmin = (tmin < t0) ? t0 : tmin;
+            tmax = (t1 < tmax) ? t1 : tmax;
+            if (hit && (tmax < tmin)) hit = false;
+        }
+        const float dist = forward_distance(hit, tmin, tmax);
+        if (dist < kInfF) {
+            float ck = any_hit ? -static_cast<float>(k) : dist;
+            uint32_t cs = k;
 #pragma unroll
-                for (int j = 0; j < kCandMax; ++j) {
-                    const bool sw = (slot[j] == PT_NO_NODE) || (ck < key[j]) || (ck == key[j] && cs < slot[j]);
-                    const float tk = key[j];
-                    const uint32_t ts = slot[j];
-                    key[j] = sw ? ck : tk;
-                    slot[j] = sw ? cs : ts;
-                    ck = sw ? tk : ck;
-                    cs = sw ? ts : cs;
-                }
-            }
-            if (sp == 0) break;
-            cur = s_stack[--sp][tid];
-        } else {
-            const DevNode& nd = sc.tlas[cur];
-            const bool l = enters(nd.l_lo, nd.l_hi), r = enters(nd.r_lo, nd.r_hi);
-            if (l && r) {
-                if (sp < kTlasStack) s_stack[sp++][tid] = nd.right;
-                cur = nd.left;
-            } else if (l || r) {
-                cur = l ? nd.left : nd.right;
-            } else {
-                if (sp == 0) break;
-                cur = s_stack[--sp][tid];
+            for (int j = 0; j < kCandMax; ++j) {
+                const bool sw = (slot[j] == PT_NO_NODE) || (ck < key[j]) || (ck == key[j] && cs < slot[j]);
+                const float tk = key[j];
+                const uint32_t ts = slot[j];
+                key[j] = sw ? ck : tk;
+                slot[j] = sw ? cs : ts;
+                ck = sw ? tk : ck;
+                cs = sw ? ts : cs;
             }
         }
     }

@@ -731,79 +731,53 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
 
     // ---- a tree over the instances' boxes when there are many of them (the instance pass then culls before it tests) ----
     // Balanced by count (median split along the widest axis of the box centres), so its depth is ceil(log2(n)).
-    std::vector<ptd::DevNode> tlas;
+    std::vector<ptd::TlasNode> tlas;
     const char* tlas_env = std::getenv("PTGPU_TLAS");  // "linear": every ray tests every bound whatever their number (cross-check)
     if (table.instances.size() > ptd::kTlasLinearMax && !(tlas_env && !std::strcmp(tlas_env, "linear"))) {
-        struct Range {
-            uint32_t begin, end, node;
-            bool right;
-        };
         std::vector<uint32_t> order(table.instances.size());
         for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
-        auto box_of = [&](uint32_t begin, uint32_t end, float* lo, float* hi) {
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::numeric_limits<float>::max();
-                hi[a] = std::numeric_limits<float>::lowest();
-            }
-            for (uint32_t i = begin; i < end; ++i) {
-                const float* d = table.instances[order[i]].dop;
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = std::min(lo[a], d[2 * a]);
-                    hi[a] = std::max(hi[a], d[2 * a + 1]);
-                }
-            }
+        // depth-first emission with an explicit work list: a range becomes a node, then its left half, then its right half;
+        // `skip` = the index after the node's subtree = node + 2 * count - 1
+        struct Range {
+            uint32_t begin, end;
         };
-        tlas.emplace_back();
-        std::vector<Range> todo;
-        auto split = [&](uint32_t begin, uint32_t end, uint32_t node) {
+        std::vector<Range> todo{{0u, static_cast<uint32_t>(order.size())}};
+        while (!todo.empty()) {
+            const Range r = todo.back();
+            todo.pop_back();
+            const uint32_t count = r.end - r.begin;
+            ptd::TlasNode nd;
             float clo[3], chi[3];
             for (int a = 0; a < 3; ++a) {
-                clo[a] = std::numeric_limits<float>::max();
-                chi[a] = std::numeric_limits<float>::lowest();
+                nd.lo[a] = clo[a] = std::numeric_limits<float>::max();
+                nd.hi[a] = chi[a] = std::numeric_limits<float>::lowest();
             }
-            for (uint32_t i = begin; i < end; ++i) {
+            for (uint32_t i = r.begin; i < r.end; ++i) {
                 const float* d = table.instances[order[i]].dop;
                 for (int a = 0; a < 3; ++a) {
+                    nd.lo[a] = std::min(nd.lo[a], d[2 * a]);
+                    nd.hi[a] = std::max(nd.hi[a], d[2 * a + 1]);
                     const float c = d[2 * a] + d[2 * a + 1];
                     clo[a] = std::min(clo[a], c);
                     chi[a] = std::max(chi[a], c);
                 }
             }
+            nd.skip = static_cast<uint32_t>(tlas.size()) + 2u * count - 1u;
+            nd.inst = (count == 1) ? order[r.begin] : PT_NO_NODE;
+            tlas.push_back(nd);
+            if (count == 1) continue;
             int axis = 0;
             for (int a = 1; a < 3; ++a)
                 if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-            const uint32_t mid = begin + (end - begin) / 2;
-            std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end, [&](uint32_t x, uint32_t y) {
+            const uint32_t mid = r.begin + count / 2;
+            std::nth_element(order.begin() + r.begin, order.begin() + mid, order.begin() + r.end, [&](uint32_t x, uint32_t y) {
                 const float* dx = table.instances[x].dop;
                 const float* dy = table.instances[y].dop;
                 const float cx = dx[2 * axis] + dx[2 * axis + 1], cy = dy[2 * axis] + dy[2 * axis + 1];
                 return cx < cy || (cx == cy && x < y);
             });
-            todo.push_back({mid, end, node, true});
-            todo.push_back({begin, mid, node, false});
-        };
-        split(0, static_cast<uint32_t>(order.size()), 0);
-        while (!todo.empty()) {
-            const Range r = todo.back();
-            todo.pop_back();
-            float lo[3], hi[3];
-            box_of(r.begin, r.end, lo, hi);
-            uint32_t ref;
-            if (r.end - r.begin == 1) {
-                ref = PT_LEAF_BIT | order[r.begin];
-            } else {
-                ref = static_cast<uint32_t>(tlas.size());
-                tlas.emplace_back();
-                split(r.begin, r.end, ref);
-            }
-            ptd::DevNode& p = tlas[r.node];
-            if (r.right) {
-                std::memcpy(p.r_lo, lo, 12); std::memcpy(p.r_hi, hi, 12);
-                p.right = ref;
-            } else {
-                std::memcpy(p.l_lo, lo, 12); std::memcpy(p.l_hi, hi, 12);
-                p.left = ref;
-            }
+            todo.push_back({mid, r.end});    // popped after the whole left half
+            todo.push_back({r.begin, mid});
         }
     }
 
@@ -1093,7 +1067,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.n_instances = static_cast<uint32_t>(table.instances.size());
     sc.n_top_nodes = n_top;
     sc.nodes4 = wide.empty() ? nullptr : c->nodes4.as<ptd::Node4>();
-    sc.tlas = tlas.empty() ? nullptr : c->tlas.as<ptd::DevNode>();
+    sc.tlas = tlas.empty() ? nullptr : c->tlas.as<ptd::TlasNode>();
+    sc.n_tlas = static_cast<uint32_t>(tlas.size());
     sc.n_top_nodes4 = n_top4;
     sc.env_w = env_w;
     sc.env_h = env_h;
