@@ -87,11 +87,28 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
         s.set_settings(st_abi)
         _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
         rate = st.rays / max(st.seconds, 1e-9)
+    # the same port on one thread, on a quarter of the band at the probe's sample count (a few seconds)
+    one_rows = (rows[0], min(rows[1], rows[0] + 4))
+    s.set_settings(abi.Settings(probe_spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
+                                abi.FLAG_SINGLE_PATH if cfg.get("single") else 0))
+    _, st1 = s.render_frame(w, h, n_threads=1, rows=one_rows)
     s.close()
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
     return {
         "value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
         "sample": f"rows {rows[0]}-{rows[1]} of {h} x {w} px at {spp} spp, {cfg['bounces']} bounces: "
                   f"{st.rays} rays in {st.seconds:.2f} s (oracle/pt_oracle.cc, libm math)",
+        "one_thread": {"value": round(st1.rays / max(st1.seconds, 1e-9) / 1e6, 4), "unit": "Mrays/s",
+                       "sample": f"rows {one_rows[0]}-{one_rows[1]} at {probe_spp} spp: {st1.rays} rays in {st1.seconds:.2f} s"},
+        "cpu_model": cpu_model, "hardware_threads": os.cpu_count(),
     }
 
 
