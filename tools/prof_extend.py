@@ -18,7 +18,7 @@ st = H.settings(program=prog, spp=spp, bounces=6 if prog == 2 else 1, newrays=8 
 g = H.make_gpu(model, env, st, w, h)
 for i in range(reps):
     t = time.time(); img, s = H.gpu_render(g, w, h); dt = time.time() - t
-    print(f"rep {i}: wall {dt*1e3:.1f} ms total {s.total_ms:.1f} extend {s.extend_ms:.1f} shade {s.shade_ms:.1f} gen {s.generate_ms:.1f} "
+    print(f"rep {i}: wall {dt*1e3:.1f} ms total {s.total_ms:.1f} extend {s.extend_ms:.1f} (instance pass {s.extend_ms - s.traverse_ms:.2f}) shade {s.shade_ms:.1f} gen {s.generate_ms:.1f} "
           f"rays {s.rays} launches {s.extend_launches} Mrays/s {s.rays/dt/1e6:.1f} extend-only {s.rays/s.extend_ms/1e3:.1f}", flush=True)
 
 img, c = g.render_counted(w, h)
