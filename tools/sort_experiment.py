@@ -13,7 +13,8 @@ import helpers as H
 from pathtracer_amd import scenes, image_io
 model = scenes.readme_standin(detail=1.0)
 env = image_io.load_hdr(os.path.join(root, "assets", "farmland_overcast_1k.hdr"))
-g = H.make_gpu(model, env, H.settings(program=2, spp=8, bounces=6, newrays=0), 800, 600)
+wide = os.environ.get("WIDE", "1") != "0"
+g = H.make_gpu(model, env, H.settings(program=2, spp=int(os.environ.get("SPP", "8")), bounces=6, newrays=0, wide=wide), 800, 600)
 if mode == "dump":
     H.gpu_render(g, 800, 600)
     print("dumped", os.path.getsize(path))
@@ -23,19 +24,24 @@ o = np.ascontiguousarray(raw[0, :, :3]); d = np.ascontiguousarray(raw[1, :, :3])
 n = o.shape[0]
 if mode == "sorted":
     lo = o.min(0); hi = o.max(0)
-    cell = np.clip(((o - lo) / np.maximum(hi - lo, 1e-9) * 16).astype(np.int64), 0, 15)
+    order = sys.argv[2] if len(sys.argv) > 2 else "od"
+    bits = 10 if order == "fine" else 4
+    if order == "hit":  # cells of the point the ray came from are replaced by where it goes: origin + direction * (scene size / 4)
+        o_key = o + d * float(np.linalg.norm(hi - lo)) * 0.25
+    else:
+        o_key = o
+    cell = np.clip(((o_key - lo) / np.maximum(hi - lo, 1e-9) * (1 << bits)).astype(np.int64), 0, (1 << bits) - 1)
     def spread(v):
-        v = (v | (v << 8)) & 0x00F00F
-        v = (v | (v << 4)) & 0x0C30C3
-        v = (v | (v << 2)) & 0x249249
-        return v
+        r = np.zeros_like(v)
+        for b in range(bits):
+            r |= ((v >> b) & 1) << (3 * b)
+        return r
     morton = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
     octant = (d[:, 0] < 0).astype(np.int64) | ((d[:, 1] < 0).astype(np.int64) << 1) | ((d[:, 2] < 0).astype(np.int64) << 2)
-    order = sys.argv[2] if len(sys.argv) > 2 else "od"
     key = ((octant << 12) | morton) if order == "od" else ((morton << 3) | octant)
     perm = np.argsort(key, kind="stable")
     o = np.ascontiguousarray(o[perm]); d = np.ascontiguousarray(d[perm])
 for rep in range(3):
     t0 = time.perf_counter()
     hits = g.intersect_rays(o, d)
-    print(mode, "rays", n, "wall ms", (time.perf_counter() - t0) * 1e3, "hit frac", float((hits["hit"] != 0).mean()), flush=True)
+    print(mode, sys.argv[2:], "rays", n, "wall ms", round((time.perf_counter() - t0) * 1e3, 1), "hit frac", float((hits["hit"] != 0).mean()), flush=True)

@@ -1,11 +1,21 @@
 #!/bin/bash
+# usage (GPU box, repo root): tools/sort_experiment.sh [launch]   -> traversal kernel time per ordering, from rocprofv3
 set -e
 root=$GRAFT_REPO_ROOT
+out=$root/gpurun_out/sortexp
+rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 120 python3 $root/tools/sort_experiment.py dump 12
-for m in "plain" "sorted od" "sorted do"; do
-  tag=$(echo $m | tr ' ' '_')
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/se_$tag -- python3 $root/tools/sort_experiment.py $m > /tmp/se_$tag.log 2>&1
-  tail -3 /tmp/se_$tag.log
-  grep -h "traverse_kernel\|tlas_kernel" $(find /tmp/se_$tag -name "*kernel_stats.csv") | cut -c1-30,150-400
+timeout -k 10 200 python3 -u $root/tools/sort_experiment.py dump ${1:-5} 2>&1 | grep -v amdgpu
+for mode in "plain" "sorted od" "sorted fine" "sorted hit"; do
+  tag=$(echo $mode | tr ' ' '_')
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag -- python3 $root/tools/sort_experiment.py $mode > $out/$tag.log 2>&1
+  tail -1 $out/$tag.log
+  python3 - "$out/$tag" "$mode" <<'PY'
+import sys, glob, csv
+f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if "traverse_kernel" in r["Name"] or "tlas_kernel" in r["Name"]:
+        print("   ", sys.argv[2], r["Name"][:40], "calls", r["Calls"], "avg_us", round(float(r["AverageNs"]) / 1e3, 1))
+PY
+  find $out/$tag -name "*kernel_trace.csv" -delete
 done
