@@ -1219,7 +1219,10 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
     if (!c || (n && (!origins || !directions || !out))) return PTGPU_E_INVALID;
     if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays: no scene loaded");
     PT_HIP(c, hipSetDevice(c->device));
-    const uint64_t K = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(c->chunk, 1u << 22), n), 64);
+    // rays per pass: 4 Mi unless PTGPU_INTERSECT_CHUNK says otherwise (experiments with launch-sized passes)
+    const char* cap_env = std::getenv("PTGPU_INTERSECT_CHUNK");
+    const uint64_t cap = cap_env ? std::max<uint64_t>(std::strtoull(cap_env, nullptr, 10), 64) : (1u << 22);
+    const uint64_t K = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(c->chunk, cap), n), 64);
     int rc = ensure_work_memory(c, 0, 0, K, K);
     if (rc) return rc;
     hipStream_t st = c->stream;

@@ -25,7 +25,7 @@ n = o.shape[0]
 if mode == "sorted":
     lo = o.min(0); hi = o.max(0)
     order = sys.argv[2] if len(sys.argv) > 2 else "od"
-    bits = 10 if order == "fine" else 4
+    bits = 10 if order == "fine" else (int(order[4:]) if order.startswith("bits") else 4)
     if order == "hit":  # cells of the point the ray came from are replaced by where it goes: origin + direction * (scene size / 4)
         o_key = o + d * float(np.linalg.norm(hi - lo)) * 0.25
     else:
@@ -38,7 +38,7 @@ if mode == "sorted":
         return r
     morton = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
     octant = (d[:, 0] < 0).astype(np.int64) | ((d[:, 1] < 0).astype(np.int64) << 1) | ((d[:, 2] < 0).astype(np.int64) << 2)
-    key = ((octant << 12) | morton) if order == "od" else ((morton << 3) | octant)
+    key = ((octant << 12) | morton) if order == "od" else (morton if order.startswith("bits") else ((morton << 3) | octant))
     perm = np.argsort(key, kind="stable")
     o = np.ascontiguousarray(o[perm]); d = np.ascontiguousarray(d[perm])
 for rep in range(3):

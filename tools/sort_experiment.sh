@@ -6,7 +6,8 @@ out=$root/gpurun_out/sortexp
 rm -rf $out && mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 python3 -u $root/tools/sort_experiment.py dump ${1:-5} 2>&1 | grep -v amdgpu
-for mode in "plain" "sorted od" "sorted fine" "sorted hit"; do
+IFS=";" read -ra modes <<< "${MODES:-plain;sorted od;sorted fine}"
+for mode in "${modes[@]}"; do
   tag=$(echo $mode | tr ' ' '_')
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$tag -- python3 $root/tools/sort_experiment.py $mode > $out/$tag.log 2>&1
   tail -1 $out/$tag.log
