@@ -421,6 +421,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
 #pragma unroll
     for (int i = 0; i < 7; ++i) finite = finite && (fabsf(pr.ip[i]) < kInfF);
     const bool wave_finite = __ballot(!finite) == 0ull;  // (lanes past the end of the queue have left already)
+    uint32_t wave_filled = 0;  // wave-uniform: no lane holds more candidates than this, so later list entries are empty
     for (uint32_t k = 0; k < n_inst; ++k) {
         const float dist = wave_finite ? dop_forward_distance_finite(sc.instances[k].dop, pr) : dop_forward_distance(sc.instances[k].dop, pr);
         if (__ballot(dist < kInfF) == 0ull) continue;  // no ray of this wavefront touches the instance: skip the insertion
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
             uint32_t cs = k;
 #pragma unroll
             for (int j = 0; j < kCandMax; ++j) {
+                if (static_cast<uint32_t>(j) > wave_filled) break;  // (uniform) the entry at wave_filled is empty in every lane
                 const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
                 const float tk = key[j];
                 const uint32_t ts = slot[j];
@@ -439,6 +441,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
                 cs = sw ? ts : cs;
             }
         }
+        ++wave_filled;
     }
 #pragma unroll
     for (int j = 0; j < kCandMax; ++j)
