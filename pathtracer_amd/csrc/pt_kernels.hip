@@ -1081,7 +1081,9 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
             const uint32_t pid = tile * 64u + lane;
             const uint32_t pixel = static_cast<uint32_t>(y) * cam.width + x;
             o4 = make_float4(cam.origin[0], cam.origin[1], cam.origin[2], __uint_as_float(pid));
-            d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float(max_bounces & 0xffu));
+            // bits 0-7 bounces left, bit 8 any-hit, bits 9-31 the framebuffer slot again (frames below 2^23 slots): the
+            // PBR shade kernel then needs no read of the origin record
+            d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float((max_bounces & 0xffu) | (pid << 9)));
             p4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_camera_key(seed, pixel, sample)));
         }
     }
@@ -1428,7 +1430,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
         const f3 dir = mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(rx, ry));
         const uint32_t dst = base + s * n_spawn + rank;
         out.o[dst] = make_float4(new_pos.x, new_pos.y, new_pos.z, __uint_as_float(pid));
-        out.d[dst] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(new_depth | 0x100u));
+        out.d[dst] = make_float4(dir.x, dir.y, dir.z, __uint_as_float(new_depth | 0x100u | (pid << 9)));
         out.p[dst] = make_float4(inv, inv, inv, __uint_as_float(rng_child(key, LOBE_AO0 + s)));
     }
 }
@@ -1480,12 +1482,13 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     bool exiting = false;
 
     if (i < n) {
-        ro = rays.o[i];
         rd = rays.d[i];
         const float4 rp = rays.p[i];
         const float4 h0 = hits.h0[i];
         const uint32_t h1 = hits.h1[i];
-        const uint32_t pid = __float_as_uint(ro.w);
+        // the framebuffer slot rides in the direction record's flag word when it fits (uniform choice per frame)
+        const uint32_t pid = (fb.stride < (1u << 23)) ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
+        ro.w = __uint_as_float(pid);
         key = __float_as_uint(rp.w);
         const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
         payload = f3{rp.x, rp.y, rp.z};
@@ -1537,7 +1540,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                     diffuse_color = (1.0f - orm.z) * alb;
                     f0 = mix3(mk3(mat.f0), alb, orm.z);
                     a_lin = orm.y * orm.y;
-                    nflags = (depth - 1u) & 0xffu;
+                    nflags = ((depth - 1u) & 0xffu) | (pid << 9);
                     u0 = rng_uniform(key, 0);
                     u1 = rng_uniform(key, 1);
                     const float u2 = rng_uniform(key, 2), u3 = rng_uniform(key, 3);

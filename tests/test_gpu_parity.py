@@ -484,6 +484,23 @@ def test_error_behaviour(tiny):
     assert exact.all()
 
 
+def test_frame_beyond_the_packed_slot_range(materials):
+    """Up to 2^23 framebuffer slots the PBR kernel takes a ray's slot from the flag word of its direction record, beyond
+    that from the origin record: a 4096x2056 frame (8.4 M slots) must match the oracle on a band of rows like smaller
+    frames do, and the AO program (which always reads the origin record) likewise."""
+    model, env = materials
+    w, h = 4096, 2056
+    rows = (1026, 1030)
+    for program, bounces, newrays in ((2, 4, 0), (1, 1, 4)):
+        st = H.settings(program=program, spp=1, bounces=bounces, newrays=newrays)
+        g, o = H.make_gpu(model, env, st, w, h), H.make_oracle(model, env, st, w, h)
+        img, s = H.gpu_render(g, w, h)
+        band, _ = o.render_frame(w, h, rows=rows)
+        assert np.isfinite(img).all() and s.camera_samples == w * h
+        d = np.abs(img[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
+        assert (d <= 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).all(), (program, d.max())
+
+
 def test_full_size_readme_frame_properties():
     """BASELINE configuration 3 at full resolution (800x600, 6 bounces) on the ~1.2M-triangle stand-in,
     at 2 spp to bound the run time: a 16-row band must match the oracle, the frame must be finite, and
