@@ -184,12 +184,18 @@ def main() -> None:
     r.update_camera_transform_state(cam.position, cam.direction, cam.up, Perspective(cam.yfov, cam.znear, w / h, cam.zfar))
 
     buf = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    # Render, reduce and resolve are ordered by ONE stream of torch's: the library launches on the handle it is given, and
+    # an RCCL reduce makes torch's CURRENT stream (not the host) wait for it, so the stream has to be the same and has to
+    # be current.  (torch's default stream has the handle 0, which the library reads as "use the context's own stream".)
+    work_stream = torch.cuda.Stream()
+    stream = work_stream.cuda_stream
+    assert stream != 0
 
     def step():
-        st = r.render_frame_sums(w, h, buf.data_ptr(), stream)
-        combine_partial_sums(buf, cfg["spp"], rank, world,
-                             resolve=lambda b: r.resolve_sums(w, h, b.data_ptr(), cfg["spp"], stream))
+        with torch.cuda.stream(work_stream):
+            st = r.render_frame_sums(w, h, buf.data_ptr(), stream)
+            combine_partial_sums(buf, cfg["spp"], rank, world,
+                                 resolve=lambda b: r.resolve_sums(w, h, b.data_ptr(), cfg["spp"], stream))
         return st
 
     def fence():

@@ -245,8 +245,11 @@ int ptgpu_render_frame(ptgpu_ctx* ctx, int width, int height, float* out_rgba, p
 /* Device-resident variant for multi-GPU sample split: leaves the SUM over this
  * context's sample subset in `d_sum_rgba` (width*height*4 floats on the
  * context's device, alpha channel = number of samples summed) without dividing.
- * `stream` is a hipStream_t (NULL = the context's own stream); the call returns
- * after the work has completed on that stream. */
+ * `stream` is a hipStream_t; the call returns after the work has completed on
+ * that stream.  NULL does NOT mean the legacy default stream: it selects the
+ * context's own non-blocking stream, which is ordered with nothing else — a
+ * caller that chains other device work (a collective, a copy) around this call
+ * must create a stream, pass its handle here and issue that work on it too. */
 int ptgpu_render_frame_sums(ptgpu_ctx* ctx, int width, int height, float* d_sum_rgba, void* stream,
                             ptgpu_stats* stats);
 

@@ -99,6 +99,9 @@ void launch_clear(hipStream_t st, float* p, uint64_t n);
 void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha);
 // row-major RGBA sums -> means in place: rgb /= divisor, a = 1
 void launch_divide_rgba(hipStream_t st, float* rgba, uint64_t n_pixels, float divisor);
+// The first launch failure since the last call (hipSuccess if none) and the name of the kernel it happened to; clears it.
+// Launchers return nothing, so callers ask here before they trust what a launch should have written.
+hipError_t take_launch_error(const char** kernel);
 void launch_pack_rays(hipStream_t st, const float* origins, const float* directions, const uint8_t* any_hit, uint32_t n,
                       RayQueue out);
 

@@ -1698,27 +1698,53 @@ __global__ __launch_bounds__(kBlock) void pack_rays_kernel(const float* __restri
 
 inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + kBlock - 1) / kBlock); }
 
+// A launch that the runtime rejects (too much LDS, too many registers, a bad grid) returns nothing: the error is only in
+// hipGetLastError, and a later synchronise succeeds as if the kernel had run.  Every launcher below therefore asks right
+// after the launch and keeps the first failure, with the kernel's name, for the caller to collect.
+thread_local hipError_t g_launch_error = hipSuccess;
+thread_local const char* g_launch_kernel = "";
+inline void note_launch(const char* kernel) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess && g_launch_error == hipSuccess) {
+        g_launch_error = e;
+        g_launch_kernel = kernel;
+    }
+}
+#define PT_LAUNCH(kernel, ...)                      \
+    do {                                            \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);    \
+        note_launch(#kernel);                       \
+    } while (0)
+
 }  // namespace
+
+hipError_t take_launch_error(const char** kernel) {
+    const hipError_t e = g_launch_error;
+    if (kernel) *kernel = g_launch_kernel;
+    g_launch_error = hipSuccess;
+    g_launch_kernel = "";
+    return e;
+}
 
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
                      uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count) {
     if (!n) return;
     if (cam.width % kTile == 0 && cam.height % kTile == 0)
-        hipLaunchKernelGGL(generate_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
+        PT_LAUNCH(generate_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
                            sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
     else
-        hipLaunchKernelGGL(generate_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
+        PT_LAUNCH(generate_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
                            sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
 }
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters) {
     if (!n) return;
     if (counters)
-        hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
+        PT_LAUNCH(extend_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
                            hits.h1, spill, spill_depth, spill_stride, counters);
     else
-        hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
+        PT_LAUNCH(extend_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
                            hits.h1, spill, spill_depth, spill_stride, counters);
 }
 uint32_t extend_persistent_grid(int device) {
@@ -1734,33 +1760,36 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
     if (!n) return;
     const uint32_t grid = std::min<uint32_t>(n_blocks, blocks_for(n));
     const uint32_t stride = n_blocks * kBlock;  // one spill column per persistent thread
-    (void)hipMemsetAsync(next_ray, 0, 8 * kCursorStride * sizeof(uint32_t), st);
-    (void)hipMemsetAsync(overflow, 0, sizeof(uint32_t), st);
+    for (hipError_t e : {hipMemsetAsync(next_ray, 0, 8 * kCursorStride * sizeof(uint32_t), st), hipMemsetAsync(overflow, 0, sizeof(uint32_t), st)})
+        if (e != hipSuccess && g_launch_error == hipSuccess) {
+            g_launch_error = e;
+            g_launch_kernel = "hipMemsetAsync of the traversal cursors";
+        }
     const dim3 g_all(blocks_for(n)), g_p(grid), g_c(std::min<uint32_t>(n_blocks, 64u)), b(kBlock);
     if (counters) {
-        if (sc.tlas) hipLaunchKernelGGL(tlas_tree_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
-        else hipLaunchKernelGGL(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        else PT_LAUNCH(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         if (sc.nodes4)
-            hipLaunchKernelGGL((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+            PT_LAUNCH((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         else
-            hipLaunchKernelGGL((traverse_kernel<true, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+            PT_LAUNCH((traverse_kernel<true, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
-        hipLaunchKernelGGL(extend_overflow_kernel<true>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
+        PT_LAUNCH(extend_overflow_kernel<true>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
                            spill_depth, stride, counters);
     } else {
-        if (sc.tlas) hipLaunchKernelGGL(tlas_tree_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
-        else hipLaunchKernelGGL(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
+        else PT_LAUNCH(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         if (sc.nodes4)
-            hipLaunchKernelGGL((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+            PT_LAUNCH((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         else
-            hipLaunchKernelGGL((traverse_kernel<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+            PT_LAUNCH((traverse_kernel<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         // continuation of the rare rays with more candidate instances than the lists hold (returns at once when none)
-        hipLaunchKernelGGL(extend_overflow_kernel<false>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
+        PT_LAUNCH(extend_overflow_kernel<false>, g_c, b, 0, st, sc, rays.o, rays.d, cand, overflow, hits.h0, hits.h1, spill,
                            spill_depth, stride, counters);
     }
 }
@@ -1769,36 +1798,36 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
     if (!n) return;
     const dim3 grid(blocks_for(n)), block(kBlock);
     if (program == 1)
-        hipLaunchKernelGGL(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
+        PT_LAUNCH(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
     else if (program == 2 && single_path)
-        hipLaunchKernelGGL(shade_pbr_kernel<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
+        PT_LAUNCH(shade_pbr_kernel<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
                            out, out_count, fb);
     else if (program == 2)
-        hipLaunchKernelGGL(shade_pbr_kernel<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
+        PT_LAUNCH(shade_pbr_kernel<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
                            out, out_count, fb);
     else
-        hipLaunchKernelGGL(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
+        PT_LAUNCH(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
 }
 void launch_clear(hipStream_t st, float* p, uint64_t n) {
     if (!n) return;
     const uint64_t n4 = n / 4;  // callers pad to a multiple of 4 floats
     uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n4 + kBlock - 1) / kBlock, 2048));
-    hipLaunchKernelGGL(clear_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, reinterpret_cast<float4*>(p), n4);
+    PT_LAUNCH(clear_kernel, dim3(grid ? grid : 1), dim3(kBlock), 0, st, reinterpret_cast<float4*>(p), n4);
 }
 void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha) {
     const uint64_t npix = static_cast<uint64_t>(cam.width) * cam.height;
-    hipLaunchKernelGGL(resolve_kernel, dim3(blocks_for(npix)), dim3(kBlock), 0, st, fb, cam,
+    PT_LAUNCH(resolve_kernel, dim3(blocks_for(npix)), dim3(kBlock), 0, st, fb, cam,
                        reinterpret_cast<float4*>(out_rgba), divisor, alpha);
 }
 void launch_divide_rgba(hipStream_t st, float* rgba, uint64_t n_pixels, float divisor) {
     if (!n_pixels) return;
-    hipLaunchKernelGGL(divide_rgba_kernel, dim3(blocks_for(n_pixels)), dim3(kBlock), 0, st, reinterpret_cast<float4*>(rgba),
+    PT_LAUNCH(divide_rgba_kernel, dim3(blocks_for(n_pixels)), dim3(kBlock), 0, st, reinterpret_cast<float4*>(rgba),
                        n_pixels, divisor);
 }
 void launch_pack_rays(hipStream_t st, const float* origins, const float* directions, const uint8_t* any_hit, uint32_t n,
                       RayQueue out) {
     if (!n) return;
-    hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, origins, directions, any_hit, n, out);
+    PT_LAUNCH(pack_rays_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, origins, directions, any_hit, n, out);
 }
 
 }  // namespace ptd

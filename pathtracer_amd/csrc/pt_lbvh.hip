@@ -230,6 +230,16 @@ __global__ __launch_bounds__(kThreads) void emit_kernel(uint32_t n_inner, uint32
             return false;                                                                       \
         }                                                                                       \
     } while (0)
+// a kernel launch and the check that the runtime accepted it (a rejected launch is reported by hipGetLastError only)
+#define LB_LAUNCH(kernel, ...)                                                                  \
+    do {                                                                                        \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                                                \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) {                                                                 \
+            if (err) *err = std::string("launch of " #kernel " failed: ") + hipGetErrorString(e_); \
+            return false;                                                                       \
+        }                                                                                       \
+    } while (0)
 
 }  // namespace
 
@@ -281,7 +291,7 @@ bool build_mesh_tree_lbvh(const ptgpu_vertex* vertices, const uint32_t* indices,
     LB_HIP(d_boxes.alloc(sizeof(Box6) * n_inner));
     LB_HIP(hipMemcpyAsync(d_tris.p, out.tris.data(), sizeof(ptd::DevTri) * n, hipMemcpyHostToDevice, st));
 
-    hipLaunchKernelGGL(morton_kernel, dim3(g_n), dim3(kThreads), 0, st, d_tris.as<ptd::DevTri>(), n, make_float3(lo[0], lo[1], lo[2]),
+    LB_LAUNCH(morton_kernel, dim3(g_n), dim3(kThreads), 0, st, d_tris.as<ptd::DevTri>(), n, make_float3(lo[0], lo[1], lo[2]),
                        make_float3(inv[0], inv[1], inv[2]), d_keys.as<uint64_t>(), d_order.as<uint32_t>());
     size_t tmp_bytes = 0, scan_bytes = 0;
     LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_order.as<uint32_t>(),
@@ -290,15 +300,15 @@ bool build_mesh_tree_lbvh(const ptgpu_vertex* vertices, const uint32_t* indices,
     LB_HIP(d_tmp.alloc(std::max(tmp_bytes, scan_bytes)));
     LB_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_order.as<uint32_t>(),
                                                d_order2.as<uint32_t>(), static_cast<int>(n), 0, 63, st));
-    hipLaunchKernelGGL(gather_kernel, dim3(g_n), dim3(kThreads), 0, st, d_tris.as<ptd::DevTri>(), d_order2.as<uint32_t>(), n,
+    LB_LAUNCH(gather_kernel, dim3(g_n), dim3(kThreads), 0, st, d_tris.as<ptd::DevTri>(), d_order2.as<uint32_t>(), n,
                        d_sorted.as<ptd::DevTri>());
-    hipLaunchKernelGGL(radix_tree_kernel, dim3(g_i), dim3(kThreads), 0, st, d_keys2.as<uint64_t>(), static_cast<int>(n), d_left.as<uint32_t>(),
+    LB_LAUNCH(radix_tree_kernel, dim3(g_i), dim3(kThreads), 0, st, d_keys2.as<uint64_t>(), static_cast<int>(n), d_left.as<uint32_t>(),
                        d_right.as<uint32_t>(), d_first.as<uint32_t>(), d_last.as<uint32_t>(), d_parent.as<uint32_t>(),
                        d_leaf_parent.as<uint32_t>());
     LB_HIP(hipMemsetAsync(d_arrivals.p, 0, 4ull * n_inner, st));
-    hipLaunchKernelGGL(fit_kernel, dim3(g_n), dim3(kThreads), 0, st, d_sorted.as<ptd::DevTri>(), n, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
+    LB_LAUNCH(fit_kernel, dim3(g_n), dim3(kThreads), 0, st, d_sorted.as<ptd::DevTri>(), n, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
                        d_parent.as<uint32_t>(), d_leaf_parent.as<uint32_t>(), d_arrivals.as<uint32_t>(), d_boxes.as<Box6>());
-    hipLaunchKernelGGL(keep_kernel, dim3(g_i), dim3(kThreads), 0, st, d_first.as<uint32_t>(), d_last.as<uint32_t>(), n_inner, max_leaf,
+    LB_LAUNCH(keep_kernel, dim3(g_i), dim3(kThreads), 0, st, d_first.as<uint32_t>(), d_last.as<uint32_t>(), n_inner, max_leaf,
                        d_keep.as<uint32_t>());
     LB_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, scan_bytes, d_keep.as<uint32_t>(), d_compact.as<uint32_t>(), static_cast<int>(n_inner), st));
     uint32_t tail[2] = {0, 0};  // compact index and keep flag of the last radix node -> number of kept nodes
@@ -311,7 +321,7 @@ bool build_mesh_tree_lbvh(const ptgpu_vertex* vertices, const uint32_t* indices,
         return false;
     }
     LB_HIP(d_nodes.alloc(sizeof(ptd::DevNode) * n_kept));
-    hipLaunchKernelGGL(emit_kernel, dim3(g_i), dim3(kThreads), 0, st, n_inner, max_leaf, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
+    LB_LAUNCH(emit_kernel, dim3(g_i), dim3(kThreads), 0, st, n_inner, max_leaf, d_left.as<uint32_t>(), d_right.as<uint32_t>(),
                        d_first.as<uint32_t>(), d_last.as<uint32_t>(), d_keep.as<uint32_t>(), d_compact.as<uint32_t>(), d_boxes.as<Box6>(),
                        d_sorted.as<ptd::DevTri>(), d_nodes.as<ptd::DevNode>());
     out.nodes.resize(n_kept);

@@ -102,10 +102,26 @@ struct DevBuf {
     }
     hipError_t ensure(size_t n) {
         if (n <= bytes) return hipSuccess;
-        release();
+        release();  // first: the pools are tens of GB, old and new together may not fit
+        if (alloc_fails_now()) return hipErrorOutOfMemory;
         hipError_t e = hipMalloc(&p, n ? n : 16);
         if (e == hipSuccess) bytes = n;
+        else p = nullptr;
         return e;
+    }
+    // Test hook: PTGPU_TEST_FAIL_ALLOC=k makes the k-th allocation from then on (counted from 1) fail as if the device
+    // were out of memory, so the error paths can be exercised without exhausting a 288 GB device.
+    // (counted from the moment the variable's text last changed, so one process can arm it repeatedly: "3:a", "3:b", ...)
+    static bool alloc_fails_now() {
+        const char* v = std::getenv("PTGPU_TEST_FAIL_ALLOC");
+        if (!v || !*v) return false;
+        static std::string armed;
+        static long count = 0;
+        if (armed != v) {
+            armed = v;
+            count = 0;
+        }
+        return ++count == std::atol(v);
     }
     template <typename T>
     T* as() const { return static_cast<T*>(p); }
@@ -169,7 +185,18 @@ namespace {
 #define PT_HIP(ctx, call)                                                                               \
     do {                                                                                                \
         hipError_t e_ = (call);                                                                         \
-        if (e_ != hipSuccess) return (ctx)->fail(PTGPU_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+        if (e_ != hipSuccess)                                                                           \
+            return (ctx)->fail(e_ == hipErrorOutOfMemory ? PTGPU_E_NOMEM : PTGPU_E_HIP, "%s failed: %s", #call, \
+                               hipGetErrorString(e_));                                                  \
+    } while (0)
+// Wait for the stream, then ask whether every kernel launched since the last check was accepted by the runtime: a
+// rejected launch does not fail the synchronise, it just never wrote what the host is about to read.
+#define PT_SYNC(ctx, st)                                                                                \
+    do {                                                                                                \
+        PT_HIP(ctx, hipStreamSynchronize(st));                                                          \
+        const char* k_ = "";                                                                            \
+        const hipError_t le_ = ptd::take_launch_error(&k_);                                             \
+        if (le_ != hipSuccess) return (ctx)->fail(PTGPU_E_HIP, "launch of %s failed: %s", k_, hipGetErrorString(le_)); \
     } while (0)
 
 template <typename T>
@@ -234,6 +261,7 @@ uint32_t fanout_of(const ptgpu_settings& s) {
 
 // K = camera samples per batch (sizes the ray pools), L = largest launch (sizes hit records, candidate lists, overflow list)
 int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t K, uint64_t L) {
+    (void)ptd::take_launch_error(nullptr);  // a launch failure left over from a call that ended early is not this call's
     K = std::max<uint64_t>(K, c->batch_cap);
     L = std::max<uint64_t>(std::max<uint64_t>(L, K), c->launch_cap);
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
@@ -241,8 +269,13 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
     const uint64_t cap_limit = (32ull << 30) / 48;  // at most 32 GiB per pool; the scheduler splits segments beyond that
     cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
+    // A failed allocation leaves its buffer empty (ensure frees first).  The sizes recorded in the context must never
+    // claim more than the buffers hold, so they are cleared before anything is touched and set again once all of it is there.
+    c->batch_cap = 0;
+    c->launch_cap = 0;
     for (Pool& p : c->pools) {
         if (p.cap < cap) {
+            p.cap = 0;
             PT_HIP(c, p.o.ensure(cap * 16));
             PT_HIP(c, p.d.ensure(cap * 16));
             PT_HIP(c, p.p.ensure(cap * 16));
@@ -387,7 +420,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         }
         PT_HIP(c, hipEventRecord(c->ev[1], st));
         PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
-        PT_HIP(c, hipStreamSynchronize(st));
+        PT_SYNC(c, st);
         PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
         out.generate_ms += ms;
         const uint32_t n_cam = *c->host_counter;
@@ -450,7 +483,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
                               (s.flags & PTGPU_FLAG_SINGLE_PATH) != 0);
             PT_HIP(c, hipEventRecord(c->ev[3], st));
             if (fanout) PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
-            PT_HIP(c, hipStreamSynchronize(st));
+            PT_SYNC(c, st);
             PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
             out.extend_ms += ms;
             if (c->persistent) {
@@ -471,7 +504,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         ptd::launch_resolve(st, fb, g.cam, d_rgba, mean ? n_samples : 1.0f, mean ? 1.0f : n_samples);
     }
     PT_HIP(c, hipEventRecord(c->ev[5], st));
-    PT_HIP(c, hipStreamSynchronize(st));
+    PT_SYNC(c, st);
     PT_HIP(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     out.total_ms = ms;
     if (counted) {
@@ -541,7 +574,8 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
         g_create_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only";
         return PTGPU_E_NODEVICE;
     }
-    auto ctx = std::make_unique<ptgpu_ctx>();
+    // owned through ptgpu_destroy from here on, so that a failure below releases the stream, events and pinned memory made so far
+    std::unique_ptr<ptgpu_ctx, void (*)(ptgpu_ctx*)> ctx(new ptgpu_ctx, &ptgpu_destroy);
     ctx->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counter), 64) != hipSuccess) {
@@ -550,6 +584,7 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
     }
     for (hipEvent_t& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) {
+            ev = nullptr;
             g_create_error = "hipEventCreate failed";
             return PTGPU_E_HIP;
         }
@@ -1161,7 +1196,7 @@ int ptgpu_resolve_sums(ptgpu_ctx* c, int width, int height, float* d_sum_rgba, u
     PT_HIP(c, hipSetDevice(c->device));
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     ptd::launch_divide_rgba(st, d_sum_rgba, static_cast<uint64_t>(width) * height, static_cast<float>(total_samples));
-    PT_HIP(c, hipStreamSynchronize(st));
+    PT_SYNC(c, st);
     return PTGPU_OK;
 }
 
@@ -1190,7 +1225,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
         ptd::launch_generate(st, g.cam, c->subs.as<float2>(), sample, 1, 0, c->settings.seed, first, n_gen, 0,
                              ptd::TileSubset{0u, 1u, g.n_tiles}, c->pools[0].at(0), c->counter.as<uint32_t>());
         PT_HIP(c, hipMemcpyAsync(c->host_counter, c->counter.p, 4, hipMemcpyDeviceToHost, st));
-        PT_HIP(c, hipStreamSynchronize(st));
+        PT_SYNC(c, st);
         const uint32_t n = *c->host_counter;
         if (!n) continue;
         run_extend(c, st, c->pools[0].at(0), n, hits, nullptr);
@@ -1200,7 +1235,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
         PT_HIP(c, hipMemcpyAsync(h0.data(), hits.h0, n * 16ull, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipMemcpyAsync(h1.data(), hits.h1, n * 4ull, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipMemcpyAsync(ro.data(), c->pools[0].o.p, n * 16ull, hipMemcpyDeviceToHost, st));
-        PT_HIP(c, hipStreamSynchronize(st));
+        PT_SYNC(c, st);
         std::vector<ptgpu_hit> dec(n);
         decode_hits(c, h0, h1, n, dec.data());
         for (uint32_t i = 0; i < n; ++i) {  // framebuffer slot (tile order) -> pixel
@@ -1244,7 +1279,7 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
         h1.resize(m);
         PT_HIP(c, hipMemcpyAsync(h0.data(), hits.h0, m * 16ull, hipMemcpyDeviceToHost, st));
         PT_HIP(c, hipMemcpyAsync(h1.data(), hits.h1, m * 4ull, hipMemcpyDeviceToHost, st));
-        PT_HIP(c, hipStreamSynchronize(st));
+        PT_SYNC(c, st);
         decode_hits(c, h0, h1, m, out + first);
     }
     return PTGPU_OK;

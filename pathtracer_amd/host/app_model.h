@@ -9,6 +9,7 @@
 #include <array>
 #include <cstdint>
 #include <filesystem>
+#include <fstream>
 #include <optional>
 #include <string>
 #include <vector>
@@ -160,6 +161,7 @@ class ModelLoader {
     Model constructModel() const { return model_; }
 
   private:
+    bool load_scene_container(std::ifstream& f, uint64_t file_bytes);
     Model model_;
 };
 

@@ -245,9 +245,27 @@ bool ModelLoader::loadFromFile(std::filesystem::path path) {
         }
         return true;
     }
+    try {
+        return load_scene_container(f, std::filesystem::file_size(path));
+    } catch (const std::exception& e) {  // length_error / bad_alloc from a header that lies about its counts
+        std::fprintf(stderr, "%s\n", e.what());
+        return false;
+    }
+}
+
+bool ModelLoader::load_scene_container(std::ifstream& f, uint64_t file_bytes) {
     uint64_t n[8];
     if (!f.read(reinterpret_cast<char*>(n), sizeof(n))) return false;
     const uint64_t nv = n[0], ni = n[1], nm = n[2], no = n[3], nmat = n[4], nimg = n[5], ntex = n[6], ncam = n[7];
+    {   // every array must fit the file: checked count by count, so no product or sum can wrap
+        const uint64_t elem[8] = {sizeof(ptgpu_vertex), 4, sizeof(ptgpu_mesh), sizeof(ptgpu_object), sizeof(ptgpu_material),
+                                  sizeof(ptgpu_image), 4, 48};
+        uint64_t left = file_bytes >= 72 ? file_bytes - 72 : 0;
+        for (int k = 0; k < 8; ++k) {
+            if (n[k] > left / elem[k]) return false;
+            left -= n[k] * elem[k];
+        }
+    }
     std::vector<ptgpu_vertex> vertices(nv);
     std::vector<uint32_t> indices(ni);
     std::vector<ptgpu_mesh> meshes(nm);
@@ -304,7 +322,8 @@ bool ModelLoader::loadFromFile(std::filesystem::path path) {
     }
     for (uint64_t i = 0; i < nimg; ++i) {
         const ptgpu_image& s = images[i];
-        if (s.width <= 0 || s.height <= 0 || s.texel_offset + static_cast<uint64_t>(s.width) * s.height > ntex) return false;
+        const uint64_t n_px = static_cast<uint64_t>(s.width > 0 ? s.width : 0) * static_cast<uint64_t>(s.height > 0 ? s.height : 0);
+        if (s.width <= 0 || s.height <= 0 || s.texel_offset > ntex || n_px > ntex - s.texel_offset) return false;
         m.images_.emplace_back(s.width, s.height,
                                std::vector<sdr_pixel>(texels.begin() + s.texel_offset, texels.begin() + s.texel_offset + static_cast<uint64_t>(s.width) * s.height));
     }

@@ -265,6 +265,13 @@ struct Asset {
         const Json* j = root.find(name);
         return (j && j->type == Json::Array) ? *j : empty;
     }
+    // A size, offset or count from the document: a JSON number that must be a non-negative integer small enough to be exact
+    // in a double (anything else would be undefined behaviour in the conversion, or land near 2^64).
+    static size_t size_field(const Json& obj, const char* name) {
+        const double v = obj.number(name, 0);
+        if (!(v >= 0.0) || v > 9007199254740992.0 || v != std::floor(v)) fail(std::string("bad ") + name + " (not a non-negative integer)");
+        return static_cast<size_t>(v);
+    }
     struct View {
         const uint8_t* data;
         size_t length, stride;
@@ -273,9 +280,11 @@ struct Asset {
         const Json& v = list("bufferViews").at(static_cast<size_t>(index));
         const long b = v.index("buffer");
         if (b < 0 || static_cast<size_t>(b) >= buffers.size()) fail("bufferView without a valid buffer");
-        const size_t off = static_cast<size_t>(v.number("byteOffset", 0)), len = static_cast<size_t>(v.number("byteLength", 0));
-        if (off + len > buffers[b].size()) fail("bufferView exceeds its buffer");
-        return View{buffers[b].data() + off, len, static_cast<size_t>(v.number("byteStride", 0))};
+        const size_t off = size_field(v, "byteOffset"), len = size_field(v, "byteLength"), stride = size_field(v, "byteStride");
+        const size_t total = buffers[b].size();
+        if (off > total || len > total - off) fail("bufferView exceeds its buffer");
+        if (stride > 252) fail("bufferView with a byteStride above 252");  // the format's limit
+        return View{buffers[b].data() + off, len, stride};
     }
     struct Accessor {
         const uint8_t* data = nullptr;
@@ -300,13 +309,19 @@ struct Asset {
             default: fail("accessor with an unknown component type");
         }
         if (!r.width) fail("accessor with an unsupported element type");
-        r.count = static_cast<size_t>(a.number("count", 0));
+        r.count = size_field(a, "count");
         const Json* n = a.find("normalized");
         r.normalized = n && n->type == Json::Bool && n->b;
         const View v = view(bv);
-        const size_t off = static_cast<size_t>(a.number("byteOffset", 0));
-        r.stride = v.stride ? v.stride : static_cast<size_t>(csize) * r.width;
-        if (r.count && off + (r.count - 1) * r.stride + static_cast<size_t>(csize) * r.width > v.length) fail("accessor exceeds its bufferView");
+        const size_t off = size_field(a, "byteOffset");
+        const size_t elem = static_cast<size_t>(csize) * r.width;
+        r.stride = v.stride ? v.stride : elem;
+        if (r.stride < elem) fail("accessor elements overlap: byteStride below the element size");
+        // range check without additions or products that could wrap: (count - 1) * stride <= length - off - elem
+        if (r.count) {
+            if (off > v.length || elem > v.length - off) fail("accessor exceeds its bufferView");
+            if ((r.count - 1) > (v.length - off - elem) / r.stride) fail("accessor exceeds its bufferView");
+        }
         r.data = v.data + off;
         return r;
     }

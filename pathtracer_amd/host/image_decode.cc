@@ -179,17 +179,21 @@ struct Huffman {
     int delta[17];
 };
 void build_huffman(Huffman& h, const uint8_t counts[16], const uint8_t* values, int n_values) {
+    // the 16 counts are file data and can declare up to 16 * 255 symbols: reject the table before anything is filled
+    int total = 0;
+    for (int len = 0; len < 16; ++len) total += counts[len];
+    if (total > 256 || total != n_values) bad("bad JPEG Huffman table");
     int k = 0;
     for (int len = 1; len <= 16; ++len)
-        for (int i = 0; i < counts[len - 1]; ++i) h.size[k++] = static_cast<uint8_t>(len);
+        for (int i = 0; i < counts[len - 1] && k < 256; ++i) h.size[k++] = static_cast<uint8_t>(len);
     h.size[k] = 0;
     h.count = k;
-    if (k != n_values || k > 256) bad("bad JPEG Huffman table");
     int code = 0;
     k = 0;
     for (int len = 1; len <= 16; ++len) {
         h.delta[len] = k - code;
         while (h.size[k] == len) h.code[k++] = static_cast<uint16_t>(code++);
+        if (code > (1 << len)) bad("bad JPEG Huffman table");  // more codes of this length than the length has
         h.maxcode[len] = code;  // first code of this length that is NOT in the table
         code <<= 1;
     }

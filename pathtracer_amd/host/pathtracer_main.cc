@@ -61,10 +61,19 @@ bool parse(int argc, char** argv, Args& a) {
         else if (k == "--wide-nodes") { a.wide_nodes = true; }
         else { std::cerr << "unknown argument " << k << "\n" << kUsage; return false; }
     }
-    if (a.model.empty()) { std::cerr << "-f is required\n" << kUsage; return false; }
-    if (a.program < 1 || a.program > 3 || a.as < 1 || a.as > 3 || a.samples < 1 || a.bounces < 0 || a.newrays < 0 || a.max_leaf < 1 ||
-        a.width < 1 || a.height < 1) {
-        std::cerr << "argument out of range\n" << kUsage;
+    // Out-of-range values are repaired, not rejected, exactly as the reference does: an enum outside its range becomes
+    // its first value (int_to_enum, src/arguments.cc:14-18: -p 9 is the ray caster, -a 0 the naive structure), counts are
+    // clamped from below (src/arguments.cc:121-132).
+    if (a.program < 1 || a.program > 3) a.program = 1;
+    if (a.as < 1 || a.as > 3) a.as = 1;
+    if (a.samples < 1) a.samples = 1;
+    if (a.bounces < 0) a.bounces = 0;
+    if (a.newrays < 0) a.newrays = 0;
+    if (a.max_leaf < 1) a.max_leaf = 1;
+    if (a.width < 1) a.width = 1;
+    if (a.height < 1) a.height = 1;
+    if (a.model.empty()) {  // src/arguments.cc:136-139: the message, then exit code 1 (src/main.cc:18-20)
+        std::cout << "A PathTracer for .gltf files on MI355X.\nUse -h or --help for usage info." << std::endl;
         return false;
     }
     return true;

@@ -210,6 +210,62 @@ def test_gltf_errors(lib, tmp_path):
         convert(lib, bad, tmp_path / "x.ptsc")
 
 
+def _patched_gltf(tmp_path, patch):
+    src = _minimal_gltf(tmp_path)
+    doc = json.loads(src.read_text())
+    patch(doc)
+    src.write_text(json.dumps(doc))
+    return src
+
+
+@pytest.mark.parametrize("patch", [
+    lambda d: d["bufferViews"][0].update(byteOffset=-8),                       # negative offset
+    lambda d: d["bufferViews"][0].update(byteOffset=1.5),                      # not an integer
+    lambda d: d["bufferViews"][0].update(byteLength=2.0 ** 63),                # beyond what a double holds exactly
+    lambda d: d["bufferViews"][0].update(byteStride=2 ** 40),                  # stride above the format's 252
+    lambda d: d["accessors"][0].update(count=2 ** 24 + 1, byteOffset=0),       # with a wrapping product this passed
+    lambda d: (d["bufferViews"][0].update(byteStride=4)),                      # elements would overlap
+    lambda d: d["accessors"][0].update(byteOffset=2 ** 62),
+    lambda d: d["accessors"][0].update(count=-3),
+], ids=["neg-offset", "fractional", "huge-length", "huge-stride", "huge-count", "stride-below-element", "huge-accessor-offset",
+        "neg-count"])
+def test_gltf_rejects_sizes_that_would_wrap(lib, tmp_path, patch):
+    with pytest.raises(RuntimeError, match="loadFromFile failed"):
+        convert(lib, _patched_gltf(tmp_path, patch), tmp_path / "x.ptsc")
+
+
+def test_scene_container_with_lying_header_is_rejected(lib, tmp_path):
+    good = tmp_path / "good.ptsc"
+    scenes.tiny_scene().save(str(good))
+    raw = bytearray(good.read_bytes())
+    for field, value in ((0, 2 ** 61), (6, 2 ** 62), (1, 2 ** 40), (7, 2 ** 63)):   # vertices, texels, indices, cameras
+        bad = bytearray(raw)
+        struct.pack_into("<Q", bad, 8 + 8 * field, value)
+        (tmp_path / "bad.ptsc").write_bytes(bytes(bad))
+        with pytest.raises(RuntimeError, match="loadFromFile failed"):
+            convert(lib, tmp_path / "bad.ptsc", tmp_path / "x.ptsc")
+    assert convert(lib, good, tmp_path / "again.ptsc") is not None
+
+
+def test_jpeg_huffman_table_declaring_too_many_symbols(lib):
+    """A DHT segment whose 16 counts sum to more than 256: rejected before any table is filled."""
+    img = PIL.fromarray(np.random.default_rng(4).integers(0, 256, (16, 16, 3), dtype=np.uint8), "RGB")
+    data = bytearray(encoded(img, "JPEG", quality=90))
+    at = data.find(b"\xff\xc4")
+    assert at > 0
+    counts = bytes([255] * 16)                      # 4080 symbols declared
+    body = bytes([0x00]) + counts + bytes(4080)
+    seg = b"\xff\xc4" + struct.pack(">H", 2 + len(body)) + body
+    with pytest.raises(RuntimeError, match="Huffman"):
+        decode(lib, bytes(data[:at]) + seg + bytes(data[at:]))
+    # counts that sum to 256 but put more codes on a length than it has
+    counts = bytes([3] + [0] * 14 + [253])
+    body = bytes([0x00]) + counts + bytes(256)
+    seg = b"\xff\xc4" + struct.pack(">H", 2 + len(body)) + body
+    with pytest.raises(RuntimeError, match="Huffman"):
+        decode(lib, bytes(data[:at]) + seg + bytes(data[at:]))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # tangents for meshes with uv but without TANGENT (the MikkTSpace algorithm, src/compute_tangents.cc:9-62).
 # Parity unpinned: the library is absent from the reference and its tests hold no tangent vectors; these are

@@ -49,12 +49,16 @@ def read_png(path):
 def test_cli_usage_errors():
     r = run("-h")
     assert r.returncode == 1 and "Usage: PathTracer" in r.stdout
-    r = run()
-    assert r.returncode == 1 and "-f is required" in r.stderr
+    r = run()  # no -f: the short message on stdout, exit code 1 (src/arguments.cc:136-139, src/main.cc:18-20)
+    assert r.returncode == 1 and "Use -h or --help for usage info." in r.stdout
     r = run("-f", "/nonexistent/scene.ptsc")
     assert r.returncode == 1 and "Failed to load model from" in r.stderr
-    r = run("-f", "x", "-p", "7")
-    assert r.returncode == 1 and "out of range" in r.stderr
+    # out-of-range values are repaired, not rejected (src/arguments.cc:14-18, 121-132): the run gets as far as loading
+    r = run("-f", "/nonexistent/scene.ptsc", "-p", "7", "-a", "0", "-s", "0", "-b", "-1", "-r", "-2", "-m", "0", "--width", "0",
+            "--height", "-5")
+    assert r.returncode == 1 and "Failed to load model from" in r.stderr and "out of range" not in r.stderr
+    r = run("-f", "x", "--no-such-flag")
+    assert r.returncode == 1 and "unknown argument" in r.stderr
 
 
 @needs_cli
@@ -113,6 +117,24 @@ def test_cli_matches_python_mirror(tmp_path):
     assert (np.abs(got[..., :3] - img[..., :3]) <= scale / 100.0).all()
     exact, _ = H.hits_equal(g.render_hits(w, h), np.fromfile(hits_path, dtype=abi.HIT_DTYPE).reshape(h, w))
     assert exact.all()
+
+
+@needs_cli
+@pytest.mark.gpu
+def test_cli_repairs_out_of_range_values_like_the_reference(tmp_path):
+    """-p 9 is the ray caster, -a 0 the naive structure, -s 0 one sample, -b -1 no bounce, -m 0 one triangle per leaf,
+    a width or height below 1 is 1 (src/arguments.cc:14-18, 121-132)."""
+    scene = tmp_path / "tiny.ptsc"
+    scenes.tiny_scene().save(str(scene))
+    a, b = tmp_path / "a.png", tmp_path / "b.png"
+    r = run("-f", scene, "-p", 9, "-a", 0, "-s", 0, "-b", -1, "-r", -3, "-m", 0, "--width", 48, "--height", 32, "-o", a)
+    assert r.returncode == 0, r.stderr
+    r = run("-f", scene, "-p", 1, "-a", 1, "-s", 1, "-b", 0, "-r", 0, "-m", 1, "--width", 48, "--height", 32, "-o", b)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(read_png(a), read_png(b))
+    r = run("-f", scene, "-p", 1, "--width", 0, "--height", -4, "-o", a)
+    assert r.returncode == 0, r.stderr
+    assert read_png(a).shape == (1, 1, 4)
 
 
 @needs_cli

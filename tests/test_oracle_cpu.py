@@ -31,6 +31,32 @@ def test_fibonacci_matches_reference_script():
     assert dy.max() < 1e-4
 
 
+def test_schlick_and_f0_against_reference_script():
+    """oracle fresnel_schlick (ray_program.cc:40-45: mix(f0, f90, (1 - c)^5), binary32) and f0_dielectric
+    (brdf.cc:70-72) against the 91 angles the reference's own double-precision script tests/fresnel_compare.py
+    evaluates for air -> glass.  Tolerance 4e-7 absolute: the values are in [0.04, 1], binary32 keeps 6e-8 there, and
+    the product x^5 is formed in four roundings (x2 = x*x, x2*x2, *x, then the mix)."""
+    from pathtracer_amd.model import f0_dielectric
+    ref = np.load(os.path.join(GOLD, "fresnel_reference.npy"))
+    f0_ref = ref[0, 3]
+    f0 = f0_dielectric(1.5, 1.0)
+    assert f0.dtype == np.float32 and abs(float(f0) - f0_ref) < 4e-9
+    one = np.ones(3, np.float32)
+    f0v = np.full(3, f0, np.float32)
+    out = np.zeros(3, np.float32)
+    worst = 0.0
+    for angle, schlick, exact, _ in ref:
+        c = np.float32(np.cos(angle))
+        ob.lib().orc_kat_schlick(f0v.ctypes.data_as(ob.abi.c_float_p), one.ctypes.data_as(ob.abi.c_float_p), c,
+                                 out.ctypes.data_as(ob.abi.c_float_p))
+        assert out[0] == out[1] == out[2]
+        worst = max(worst, abs(float(out[0]) - schlick))
+    assert worst < 4e-7, worst
+    # sanity of the vector itself: Schlick is an approximation of the exact curve, equal at 0 and 90 degrees
+    assert abs(ref[0, 1] - ref[0, 2]) < 1e-12 and abs(ref[-1, 1] - ref[-1, 2]) < 1e-12
+    assert np.abs(ref[:, 1] - ref[:, 2]).max() < 0.05
+
+
 def test_golden_kat_tables(golden):
     import sys
     sys.path.insert(0, GOLD)
