@@ -351,37 +351,10 @@ def test_loaders_survive_mutated_files(tmp_path):
     """Corrupted input must end in an error return, never in a crash or a hang: 120 seeded mutations (byte flips in the
     JSON chunk, in the binary chunk and header, truncations) of a GLB, of PNG / JPEG streams and of a scene container,
     read in a child process."""
-    import random
     import subprocess
     import sys
-    rng = random.Random(7)
-    glb = tmp_path / "s.glb"
-    gltf_export.save_glb(scenes.tiny_scene(), str(glb))
-    ptsc = tmp_path / "s.ptsc"
-    scenes.tiny_scene().save(str(ptsc))
-    img = (np.random.default_rng(0).uniform(0, 255, (23, 31, 3))).astype(np.uint8)
-    seeds = {"glb": glb.read_bytes(), "ptsc": ptsc.read_bytes()}
-    for fmt, kw in (("PNG", {}), ("JPEG", {"quality": 80, "subsampling": 2})):
-        b = io.BytesIO()
-        PIL.fromarray(img).save(b, fmt, **kw)
-        seeds[fmt.lower()] = b.getvalue()
-    paths = []
-    for name, data in seeds.items():
-        json_len = struct.unpack_from("<I", data, 12)[0] if name == "glb" else 0
-        for k in range(30):
-            m = bytearray(data)
-            kind = rng.random()
-            if kind < 0.4 and json_len:
-                for _ in range(rng.randint(1, 4)):
-                    m[rng.randrange(20, 20 + json_len)] = rng.choice(b'0123456789-[]{}",:ae ')
-            elif kind < 0.8:
-                for _ in range(rng.randint(1, 8)):
-                    m[rng.randrange(len(m))] = rng.randrange(256)
-            else:
-                m = m[:rng.randrange(1, len(m))]
-            p = tmp_path / f"{name}_{k}.{'glb' if name == 'glb' else name}"
-            p.write_bytes(m)
-            paths.append(str(p))
+    from mutations import mutated_files
+    paths = mutated_files(tmp_path)
     child = r"""
 import ctypes as C, sys
 sys.path.insert(0, sys.argv[1])
