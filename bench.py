@@ -58,41 +58,52 @@ def load_env(kind: str):
     return image_io.load_hdr(os.path.join(ROOT, "assets", "farmland_overcast_1k.hdr"))
 
 
-def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
-    """Time the CPU oracle (a port of the reference renderer, libm math) on a bounded sample of the
-    same workload: a band of image rows around the centre at reduced spp."""
+def cpu_baseline(model, env, cfg, seconds_target: float = 8.0):
+    """Time the CPU oracle (a port of the reference renderer, libm math) on a bounded sample of the same workload: a band
+    of image rows around the centre at reduced spp.  Two builds of the same source are timed: the one compiled on this
+    machine with -O3 -march=native -ffp-contract=off (the headline `value`; needs g++ at run time) and the parity build
+    the tests use (-O2 -march=x86-64-v3)."""
+    import tempfile
     from oracle import binding as ob
     from pathtracer_amd import abi
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
     w, h = cfg["width"], cfg["height"]
     cam = model.cameras[0]
+    flags = abi.FLAG_SINGLE_PATH if cfg.get("single") else 0
 
-    def scene_for(spp):
-        st = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
-                          abi.FLAG_SINGLE_PATH if cfg.get("single") else 0)
-        s = ob.OracleScene(model, env, st)
+    def settings_for(spp):
+        return abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1, flags)
+
+    rows = (max(0, h // 2 - 8), min(h, h // 2 + 8))
+    one_rows = (rows[0], min(rows[1], rows[0] + 4))
+    probe_spp = 1 if cfg["spp"] == 1 else 2
+
+    def measure(library, label):
+        s = ob.OracleScene(model, env, settings_for(probe_spp), library=library)
         s.update_camera_transform_state(cam.position, cam.direction, cam.up, cam.yfov, w / h, cam.znear, cam.zfar)
         s.set_math_mode(ob.MATH_LIBM)
-        return s
-    rows = (max(0, h // 2 - 8), min(h, h // 2 + 8))
-    probe_spp = 1 if cfg["spp"] == 1 else 2
-    s = scene_for(probe_spp)
-    _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
-    rate = st.rays / max(st.seconds, 1e-9)
-    per_spp = st.seconds / probe_spp
-    spp = int(max(probe_spp, min(cfg["spp"], seconds_target / max(per_spp, 1e-9))))
-    if spp > probe_spp:
-        st_abi = abi.Settings(spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
-                              abi.FLAG_SINGLE_PATH if cfg.get("single") else 0)
-        s.set_settings(st_abi)
         _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
-        rate = st.rays / max(st.seconds, 1e-9)
-    # the same port on one thread, on a quarter of the band at the probe's sample count (a few seconds)
-    one_rows = (rows[0], min(rows[1], rows[0] + 4))
-    s.set_settings(abi.Settings(probe_spp, cfg["bounces"], cfg["newrays"], 8, 0.0, cfg["program"], 1, 1234, 0, 1,
-                                abi.FLAG_SINGLE_PATH if cfg.get("single") else 0))
-    _, st1 = s.render_frame(w, h, n_threads=1, rows=one_rows)
-    s.close()
+        spp = int(max(probe_spp, min(cfg["spp"], seconds_target / max(st.seconds / probe_spp, 1e-9))))
+        if spp > probe_spp:
+            s.set_settings(settings_for(spp))
+            _, st = s.render_frame(w, h, n_threads=threads, rows=rows)
+        # the same build on one thread, on a quarter of the band at the probe's sample count (a few seconds)
+        s.set_settings(settings_for(probe_spp))
+        _, st1 = s.render_frame(w, h, n_threads=1, rows=one_rows)
+        s.close()
+        return {"value": round(st.rays / max(st.seconds, 1e-9) / 1e6, 4), "unit": "Mrays/s", "cores": threads, "build": label,
+                "sample": f"rows {rows[0]}-{rows[1]} of {h} x {w} px at {spp} spp, {cfg['bounces']} bounces: "
+                          f"{st.rays} rays in {st.seconds:.2f} s (oracle/pt_oracle.cc, libm math)",
+                "one_thread": {"value": round(st1.rays / max(st1.seconds, 1e-9) / 1e6, 4), "unit": "Mrays/s",
+                               "sample": f"rows {one_rows[0]}-{one_rows[1]} at {probe_spp} spp: {st1.rays} rays in {st1.seconds:.2f} s"}}
+
+    parity = measure(None, "g++ -O2 -march=x86-64-v3 -ffp-contract=off (the build the parity tests use)")
+    native = None
+    try:
+        path = ob.build_native(os.path.join(tempfile.gettempdir(), f"pt_oracle_native_{os.getuid()}"))
+        native = measure(ob.load_library(path), "g++ -O3 -march=native -ffp-contract=off, compiled on this machine")
+    except Exception as e:  # no compiler on this machine: the parity build's figure stands
+        parity["native_build_error"] = f"{type(e).__name__}: {str(e)[:200]}"
     cpu_model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -102,14 +113,13 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 12.0):
                     break
     except OSError:
         pass
-    return {
-        "value": round(rate / 1e6, 4), "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"rows {rows[0]}-{rows[1]} of {h} x {w} px at {spp} spp, {cfg['bounces']} bounces: "
-                  f"{st.rays} rays in {st.seconds:.2f} s (oracle/pt_oracle.cc, libm math)",
-        "one_thread": {"value": round(st1.rays / max(st1.seconds, 1e-9) / 1e6, 4), "unit": "Mrays/s",
-                       "sample": f"rows {one_rows[0]}-{one_rows[1]} at {probe_spp} spp: {st1.rays} rays in {st1.seconds:.2f} s"},
-        "cpu_model": cpu_model, "hardware_threads": os.cpu_count(),
-    }
+    out = dict(native or parity)
+    out["kind"] = "port"
+    out["cpu_model"] = cpu_model
+    out["hardware_threads"] = os.cpu_count()
+    if native:
+        out["parity_build"] = {k: parity[k] for k in ("value", "unit", "build", "sample", "one_thread")}
+    return out
 
 
 def main() -> None:

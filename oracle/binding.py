@@ -48,11 +48,29 @@ _lib = None
 
 def lib() -> C.CDLL:
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        build()
-    L = C.CDLL(LIB_PATH)
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = load_library(LIB_PATH)
+    return _lib
+
+
+def build_native(out_dir: str) -> str:
+    """The same source compiled for the machine it runs on (-O3 -march=native, contraction still off): the build the
+    CPU baseline of the benchmark is timed with.  Parity tests never use it — its arithmetic is the same, its code is
+    tied to one CPU model.  Returns the library's path."""
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libpt_oracle_native.so")
+    src = os.path.join(_HERE, "pt_oracle.cc")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["g++", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-pthread",
+                        "-shared", "-o", out, src], check=True, capture_output=True, timeout=300)
+    return out
+
+
+def load_library(path: str) -> C.CDLL:
+    """Load one build of the oracle and declare its entry points."""
+    L = C.CDLL(path)
     vp, P, f32p = C.c_void_p, C.POINTER, abi.c_float_p
     L.orc_scene_create.restype = vp
     L.orc_scene_create.argtypes = [P(abi.Model), P(abi.Envmap), P(abi.Settings)]
@@ -96,7 +114,6 @@ def lib() -> C.CDLL:
     L.orc_kat_rng_child.argtypes = [C.c_uint32, C.c_uint32]
     L.orc_kat_on_hit.restype = C.c_int
     L.orc_kat_on_hit.argtypes = [vp, P(OrcRay), P(abi.Hit), f32p, P(OrcRay), C.c_int]
-    _lib = L
     return L
 
 
@@ -108,8 +125,8 @@ def _f32(a):
 class OracleScene:
     """The oracle's counterpart of the reference ``Renderer`` with a scene loaded."""
 
-    def __init__(self, model, env_rgba=None, settings: abi.Settings = None):
-        self._L = lib()
+    def __init__(self, model, env_rgba=None, settings: abi.Settings = None, library: C.CDLL = None):
+        self._L = library if library is not None else lib()
         self._model = model
         cm = model.as_ctypes()
         env = None
