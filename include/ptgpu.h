@@ -272,6 +272,24 @@ int ptgpu_render_hits(ptgpu_ctx* ctx, int width, int height, uint32_t sample, pt
 int ptgpu_intersect_rays(ptgpu_ctx* ctx, uint64_t n, const float* origins, const float* directions,
                          const uint8_t* any_hit, ptgpu_hit* out);
 
+/* The same batch for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc); it has no
+ * counterpart in the reference.  Inputs and the output are device memory on
+ * the context's device (n origins and directions as xyz triples, n any-hit
+ * bytes or NULL, n hit records out); everything else the traversal needs lives
+ * in a work array that is part of the library's code object, so the call makes
+ * no hipMalloc / hipFree and no other allocation.  Limits: at most
+ * PTGPU_STATIC_MAX_RAYS rays per call (more: PTGPU_E_INVALID), and trees whose
+ * traversal stack fits the array (deeper: PTGPU_E_NOMEM).  The work is queued
+ * on `stream` (NULL = the context's own stream, see ptgpu_render_frame_sums);
+ * wait != 0 returns after it has completed, wait == 0 right after queueing.
+ * All calls on one GPU share that GPU's one array: calls that overlap in time
+ * on the same GPU (two streams, two contexts) race and must be serialised by
+ * the caller.  Results equal ptgpu_intersect_rays bit for bit. */
+#define PTGPU_STATIC_MAX_RAYS (1u << 17)
+int ptgpu_intersect_rays_static(ptgpu_ctx* ctx, uint32_t n, const float* d_origins, const float* d_directions,
+                                const uint8_t* d_any_hit, ptgpu_hit* d_out, void* stream, int wait);
+
 /* Tree statistics of one mesh BVH (MeshBVHData::collect_tree_info,
  * src/acceleration_structure.cc:538-570). */
 int ptgpu_get_bvh_info(const ptgpu_ctx* ctx, uint32_t mesh_index, ptgpu_bvh_info* out);

@@ -168,6 +168,7 @@ def declare_ptgpu(lib: C.CDLL) -> None:
         "ptgpu_render_counted": (C.c_int, [vp, C.c_int, C.c_int, c_float_p, P(Stats)]),
         "ptgpu_render_hits": (C.c_int, [vp, C.c_int, C.c_int, C.c_uint32, P(Hit)]),
         "ptgpu_intersect_rays": (C.c_int, [vp, C.c_uint64, c_float_p, c_float_p, c_u8_p, P(Hit)]),
+        "ptgpu_intersect_rays_static": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vp, vp, C.c_int]),  # device pointers
         "ptgpu_get_bvh_info": (C.c_int, [vp, C.c_uint32, P(BvhInfo)]),
         "ptgpu_subsample_positions": (C.c_int, [C.c_uint32, c_float_p]),
     }
@@ -177,10 +178,12 @@ def declare_ptgpu(lib: C.CDLL) -> None:
         fn.argtypes = args
 
 
+STATIC_MAX_RAYS = 1 << 17  # PTGPU_STATIC_MAX_RAYS
+
 PTGPU_SYMBOLS = [
     "ptgpu_create", "ptgpu_destroy", "ptgpu_last_error", "ptgpu_set_render_settings", "ptgpu_get_render_settings",
     "ptgpu_load_scene", "ptgpu_update_camera_transform_state", "ptgpu_set_camera_raw", "ptgpu_get_camera_raw",
     "ptgpu_get_scene_bound", "ptgpu_render_frame", "ptgpu_render_frame_sums", "ptgpu_resolve_sums",
-    "ptgpu_render_counted", "ptgpu_render_hits", "ptgpu_intersect_rays", "ptgpu_get_bvh_info",
+    "ptgpu_render_counted", "ptgpu_render_hits", "ptgpu_intersect_rays", "ptgpu_intersect_rays_static", "ptgpu_get_bvh_info",
     "ptgpu_subsample_positions",
 ]

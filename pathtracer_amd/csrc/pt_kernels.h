@@ -99,6 +99,9 @@ void launch_clear(hipStream_t st, float* p, uint64_t n);
 void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha);
 // row-major RGBA sums -> means in place: rgb /= divisor, a = 1
 void launch_divide_rgba(hipStream_t st, float* rgba, uint64_t n_pixels, float divisor);
+// Hit queue records of rays [0, n) as the ABI's 32-byte ptgpu_hit records, written to device memory.
+// object_mesh[object] = mesh index of an object.
+void launch_unpack_hits(hipStream_t st, HitQueue hits, const uint32_t* object_mesh, uint32_t n, void* out_records);
 // The first launch failure since the last call (hipSuccess if none) and the name of the kernel it happened to; clears it.
 // Launchers return nothing, so callers ask here before they trust what a launch should have written.
 hipError_t take_launch_error(const char** kernel);

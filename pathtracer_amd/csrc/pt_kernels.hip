@@ -1696,6 +1696,21 @@ __global__ __launch_bounds__(kBlock) void pack_rays_kernel(const float* __restri
     out.p[i] = make_float4(1.f, 1.f, 1.f, 0.f);
 }
 
+// hit queue records -> the ABI's 32-byte hit records (t, A, B, object, mesh, triangle, hit, backface), on the device
+__global__ __launch_bounds__(kBlock) void unpack_hits_kernel(const float4* __restrict__ h0, const uint32_t* __restrict__ h1,
+                                                             const uint32_t* __restrict__ object_mesh, uint32_t n,
+                                                             uint4* __restrict__ out) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = h0[i];
+    const uint32_t b = h1[i];
+    const bool hit = (b & 0x80000000u) != 0;
+    const uint32_t object = hit ? (b & 0x3fffffffu) : 0u;
+    out[2 * i] = make_uint4(__float_as_uint(hit ? a.x : kInfF), __float_as_uint(hit ? a.y : 0.0f), __float_as_uint(hit ? a.z : 0.0f), object);
+    out[2 * i + 1] = make_uint4(hit ? object_mesh[object] : 0u, hit ? __float_as_uint(a.w) : 0u, hit ? 1u : 0u,
+                                (hit && (b & 0x40000000u)) ? 1u : 0u);
+}
+
 inline uint32_t blocks_for(uint64_t n) { return static_cast<uint32_t>((n + kBlock - 1) / kBlock); }
 
 // A launch that the runtime rejects (too much LDS, too many registers, a bad grid) returns nothing: the error is only in
@@ -1828,6 +1843,12 @@ void launch_pack_rays(hipStream_t st, const float* origins, const float* directi
                       RayQueue out) {
     if (!n) return;
     PT_LAUNCH(pack_rays_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, origins, directions, any_hit, n, out);
+}
+
+void launch_unpack_hits(hipStream_t st, HitQueue hits, const uint32_t* object_mesh, uint32_t n, void* out_records) {
+    if (!n) return;
+    PT_LAUNCH(unpack_hits_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, st, hits.h0, hits.h1, object_mesh, n,
+              static_cast<uint4*>(out_records));
 }
 
 }  // namespace ptd

@@ -28,6 +28,33 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// ---- work memory of ptgpu_intersect_rays_static ------------------------------------------------------
+// That entry point may not allocate, so the buffers the traversal kernels need beyond its inputs and outputs — the ray
+// records, the candidate lists, the hit queue, the claim cursors, the overflow list and the stack spill area — are
+// carved out of one array that is part of the library's code object.  Every GPU the library runs on holds its own copy
+// from the moment the code object is loaded there until the process ends.
+constexpr uint32_t kStaticMaxRays = 1u << 17;     // rays per call
+constexpr uint32_t kStaticBlocks = 256;           // resident traversal workgroups of that call (one spill column per thread)
+constexpr uint32_t kStaticSpillDepth = 64;        // stack entries beyond the LDS part that the spill area holds per thread
+constexpr size_t align256(size_t n) { return (n + 255) & ~static_cast<size_t>(255); }
+struct StaticLayout {
+    static constexpr size_t ray_o = 0;
+    static constexpr size_t ray_d = ray_o + align256(16ull * kStaticMaxRays);
+    static constexpr size_t ray_p = ray_d + align256(16ull * kStaticMaxRays);
+    static constexpr size_t hit0 = ray_p + align256(16ull * kStaticMaxRays);
+    static constexpr size_t hit1 = hit0 + align256(16ull * kStaticMaxRays);
+    static constexpr size_t cand = hit1 + align256(4ull * kStaticMaxRays);
+    static constexpr size_t overflow = cand + align256(8ull * ptd::kCandMax * kStaticMaxRays);
+    static constexpr size_t cursors = overflow + align256(4ull * (kStaticMaxRays + 1));
+    static constexpr size_t spill = cursors + align256(1024);
+    static constexpr size_t total = spill + align256(4ull * kStaticSpillDepth * kStaticBlocks * ptd::kBlock);
+};
+static __device__ __align__(256) unsigned char scratch[StaticLayout::total];  // 34.6 MB
+// In host code `scratch` is only the symbol's stand-in; the array's address on a device is asked for once per device
+// (ptgpu_create, with that device current) and kept here.  Host code uses these pointers, never the name.
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
 // ---- host vector math with glm's operation order (camera state only) -----------------------------
 struct H3 {
     float x, y, z;
@@ -148,6 +175,8 @@ struct ptgpu_ctx {
     ptd::SceneDev scene{};
     std::vector<ptgpu_bvh_info> bvh_info;
     std::vector<uint32_t> object_mesh;  // object -> mesh index (for hit dumps)
+    DevBuf d_object_mesh;               // the same table on the device (part of the scene, filled by load_scene)
+    unsigned char* static_scratch = nullptr;  // this device's copy of the library's built-in work array
     uint32_t max_depth = 0;
     float scene_min[3] = {0, 0, 0}, scene_max[3] = {0, 0, 0};
 
@@ -588,6 +617,18 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
             g_create_error = "hipEventCreate failed";
             return PTGPU_E_HIP;
         }
+    if (device_id < kMaxDevices) {
+        if (!g_scratch_ptr[device_id]) {
+            void* p = nullptr;
+            const hipError_t es = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (es != hipSuccess || !p) {
+                g_create_error = std::string("hipGetSymbolAddress of the built-in work array failed: ") + hipGetErrorString(es);
+                return PTGPU_E_HIP;
+            }
+            g_scratch_ptr[device_id] = static_cast<unsigned char*>(p);
+        }
+        ctx->static_scratch = g_scratch_ptr[device_id];
+    }
     ptgpu_settings d{};
     d.samples_per_pixel = 1;  // defaults of arguments.cc:36-101
     d.max_ray_bounces = 4;
@@ -1088,6 +1129,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     if ((rc = upload(c, c->texels, reinterpret_cast<const uint32_t*>(model->texels), static_cast<size_t>(model->n_texels)))) return rc;
     if ((rc = upload(c, c->env, env_px, static_cast<size_t>(env_w) * env_h * 4))) return rc;
     if ((rc = upload(c, c->lut, lut, 256))) return rc;
+    if ((rc = upload(c, c->d_object_mesh, c->object_mesh.data(), c->object_mesh.size()))) return rc;
 
     ptd::SceneDev& sc = c->scene;
     sc.nodes = c->nodes.as<ptd::NodeQ>();
@@ -1282,6 +1324,40 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
         PT_SYNC(c, st);
         decode_hits(c, h0, h1, m, out + first);
     }
+    return PTGPU_OK;
+}
+
+int ptgpu_intersect_rays_static(ptgpu_ctx* c, uint32_t n, const float* d_origins, const float* d_directions,
+                                const uint8_t* d_any_hit, ptgpu_hit* d_out, void* stream, int wait) {
+    if (!c || (n && (!d_origins || !d_directions || !d_out))) return PTGPU_E_INVALID;
+    if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays_static: no scene loaded");
+    if (!c->static_scratch) return c->fail(PTGPU_E_STATE, "intersect_rays_static: device %d has no built-in work array", c->device);
+    if (n > kStaticMaxRays)
+        return c->fail(PTGPU_E_INVALID, "intersect_rays_static: %u rays in one call, the built-in work array holds %u", n, kStaticMaxRays);
+    const uint32_t spill_depth = c->max_depth > static_cast<uint32_t>(ptd::kStackLds) ? c->max_depth - ptd::kStackLds : 0;
+    if (spill_depth > kStaticSpillDepth)
+        return c->fail(PTGPU_E_NOMEM, "intersect_rays_static: the scene's trees need %u spilled stack entries per thread, the built-in work array holds %u",
+                       spill_depth, kStaticSpillDepth);
+    if (!n) return PTGPU_OK;
+    PT_HIP(c, hipSetDevice(c->device));
+    (void)ptd::take_launch_error(nullptr);
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    unsigned char* base = c->static_scratch;  // the array's address on this device (never the symbol's name)
+    const ptd::RayQueue rq{reinterpret_cast<float4*>(base + StaticLayout::ray_o), reinterpret_cast<float4*>(base + StaticLayout::ray_d),
+                           reinterpret_cast<float4*>(base + StaticLayout::ray_p)};
+    const ptd::HitQueue hits{reinterpret_cast<float4*>(base + StaticLayout::hit0), reinterpret_cast<uint32_t*>(base + StaticLayout::hit1)};
+    const ptd::CandQueue cand{reinterpret_cast<uint2*>(base + StaticLayout::cand), kStaticMaxRays};
+    ptd::launch_pack_rays(st, d_origins, d_directions, d_any_hit, n, rq);
+    // the cursors and the overflow count are cleared by the launcher (hipMemsetAsync on these addresses); every ray's hit
+    // record and candidate list is rewritten before it is read, so nothing else of the last call's contents matters
+    ptd::launch_extend_persistent(st, c->scene, rq, n, hits, cand, reinterpret_cast<uint32_t*>(base + StaticLayout::spill), spill_depth,
+                                  kStaticBlocks, reinterpret_cast<uint32_t*>(base + StaticLayout::cursors),
+                                  reinterpret_cast<uint32_t*>(base + StaticLayout::overflow), nullptr);
+    ptd::launch_unpack_hits(st, hits, c->d_object_mesh.as<uint32_t>(), n, d_out);
+    const char* kernel = "";
+    const hipError_t le = ptd::take_launch_error(&kernel);
+    if (le != hipSuccess) return c->fail(PTGPU_E_HIP, "launch of %s failed: %s", kernel, hipGetErrorString(le));
+    if (wait) PT_HIP(c, hipStreamSynchronize(st));
     return PTGPU_OK;
 }
 

@@ -229,6 +229,13 @@ class Renderer:
                                                  out.ctypes.data_as(C.POINTER(abi.Hit))))
         return out
 
+    def intersect_rays_static(self, n: int, d_origins: int, d_directions: int, d_any_hit: int, d_out: int, stream: int = 0,
+                              wait: bool = True) -> None:
+        """``ptgpu_intersect_rays_static``: the same batch on device pointers (integers), without any allocation inside
+        the library; at most ``abi.STATIC_MAX_RAYS`` rays per call."""
+        self._check(self._L.ptgpu_intersect_rays_static(self._h, n, d_origins or None, d_directions or None, d_any_hit or None,
+                                                        d_out or None, stream or None, 1 if wait else 0))
+
     def bvh_info(self, mesh_index: int) -> abi.BvhInfo:
         info = abi.BvhInfo()
         self._check(self._L.ptgpu_get_bvh_info(self._h, mesh_index, C.byref(info)))
