@@ -193,6 +193,7 @@ typedef struct ptgpu_stats {
     uint64_t wave_inner_iterations; /* idem: inner-node loop iterations summed over wavefronts */
     uint64_t wave_triangle_iterations; /* idem: triangle loop iterations summed over wavefronts */
     double traverse_ms; /* part of extend_ms spent in the traversal kernel (0 with PTGPU_EXTEND=simple) */
+    uint64_t nodes_from_lds; /* ptgpu_render_counted: node visits served by the traversal kernel's LDS copy of the top nodes */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

@@ -545,6 +545,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.instances_entered = tc.inst_entered;
         out.wave_inner_iterations = tc.wave_inner;
         out.wave_triangle_iterations = tc.wave_tri;
+        out.nodes_from_lds = tc.census[1][0];
         if (std::getenv("PTGPU_VERBOSE")) {
             std::fprintf(stderr, "[ptgpu] node visits served from LDS: %llu of %llu\n", tc.census[1][0], tc.nodes);
             static const char* names[4] = {"service", "-", "inner", "leaf"};

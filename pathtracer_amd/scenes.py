@@ -300,16 +300,33 @@ def readme_standin(detail: float = 1.0, seed: int = 7) -> SceneModel:
     return b.build()
 
 
-def stress_mesh(n_triangles: int = 10_000_000, seed: int = 11) -> SceneModel:
-    """One opaque dielectric GGX object (roughness 0.5, metallic 0, no textures), identity transform:
-    the BVH-traversal / HBM stress configuration."""
-    n = max(8, int(round(np.sqrt(n_triangles / 2.0))))
+def stress_mesh(n_triangles: int = 10_000_000, seed: int = 11, opening_deg: float = 98.0) -> SceneModel:
+    """One opaque dielectric GGX object (roughness 0.5, metallic 0, no textures), identity transform: the BVH-traversal /
+    HBM stress configuration.  The mesh is a cavern: a bumpy core (outward faces) inside a bumpy shell (inward faces) whose
+    top is open to the white environment within `opening_deg` of the pole; the camera stands between the two, so most
+    paths keep bouncing between core and shell (tens of rays per sample at 8 bounces, in every direction through every part
+    of the tree) instead of leaving for the environment after the first hit."""
+    n_outer = max(8, int(round(np.sqrt(n_triangles * 0.62 / 2.0 / (1.0 - opening_deg / 180.0)))))
+    n_inner = max(8, int(round(np.sqrt(n_triangles * 0.38 / 2.0))))
     b = ModelBuilder(f"stress_{n_triangles}")
     mat = b.add_material(base_color=(0.8, 0.8, 0.8, 1), metallic=0.0, roughness=0.5)
-    mesh = b.add_mesh(*_args(blob(n, n, 1.0, 0.25, seed=seed, octaves=9)), material=mat)
+    cp, cn, ci, cuv, ct = blob(n_inner, n_inner, 1.0, 0.25, seed=seed, octaves=9)
+    sp, sn, si, suv, st = blob(n_outer, n_outer, 2.6, 0.09, seed=seed + 1, octaves=9)
+    # the shell faces inwards (winding and normals reversed) and loses the rows of triangles around its +Y pole
+    first_row = int(np.ceil(opening_deg / 180.0 * n_outer))
+    rows = si.min(axis=1) // (n_outer + 1)   # latitude row of a triangle = row of its lowest-numbered vertex
+    si = si[rows >= first_row][:, [0, 2, 1]]
+    sn = -sn
+    pos = np.concatenate([cp, sp])
+    nrm = np.concatenate([cn, sn])
+    idx = np.concatenate([ci, si + len(cp)])
+    uv = np.concatenate([cuv, suv])
+    tan = np.concatenate([ct, st])
+    mesh = b.add_mesh(pos, nrm, idx, uv, tan, material=mat)
     b.add_object(mesh)
-    pos = np.array([0.0, 0.6, 3.1])
-    b.add_camera(Camera(position=pos, direction=_normalize(-pos), up=(0, 1, 0), yfov=np.radians(40.0), znear=0.05,
+    eye = np.array([0.35, -0.25, 1.85])
+    target = np.array([-1.6, -0.6, 0.2])
+    b.add_camera(Camera(position=eye, direction=_normalize(target - eye), up=(0, 1, 0), yfov=np.radians(55.0), znear=0.05,
                         zfar=100.0))
     return b.build()
 

@@ -576,11 +576,10 @@ def test_full_size_ambient_occlusion_properties():
 
 def test_full_size_stress_geometry_properties():
     """BASELINE configuration 4's shape — one multi-million-triangle mesh, 3840x2160, 8 bounces, white environment — at
-    1 spp (and 3 M instead of 10 M triangles unless PT_TEST_STRESS_TRIS says otherwise, to keep the CPU oracle's share
-    of the test short): the primary-hit records of the whole frame are bit-identical to the oracle's, a band of the PBR
+    1 spp, at the configuration's 10 M triangles (PT_TEST_STRESS_TRIS overrides the count): the primary-hit records of the whole frame are bit-identical to the oracle's, a band of the PBR
     frame matches,
     the BVH has the oracle's statistics, ray counts agree."""
-    n_tris = int(os.environ.get("PT_TEST_STRESS_TRIS", "3000000"))
+    n_tris = int(os.environ.get("PT_TEST_STRESS_TRIS", "10000000"))
     model = scenes.stress_mesh(n_tris)
     w, h = 3840, 2160
     st = H.settings(program=2, spp=1, bounces=8)

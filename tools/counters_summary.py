@@ -25,6 +25,9 @@ for k in kernels:
     print(f"  VALU utilisation (VALU instr x 2 clk / SIMD clk)        {g('SQ_INSTS_VALU') * 2 / simd_clk:6.3f}")
     print(f"  wave time: waiting {g('SQ_WAIT_ANY') / max(g('SQ_WAVE_CYCLES'), 1):5.3f}  issue-stalled {g('SQ_WAIT_INST_ANY') / max(g('SQ_WAVE_CYCLES'), 1):5.3f}"
           f"  issuing {g('SQ_ACTIVE_INST_ANY') / max(g('SQ_WAVE_CYCLES'), 1):5.3f}")
+    print(f"  per SIMD clock: VALU pipe active {g('SQ_ACTIVE_INST_VALU') * 4 / simd_clk:5.3f}  scalar unit active {g('SQ_ACTIVE_INST_SCA') * 4 / simd_clk / 2:5.3f}"
+          f"  LDS issue active {g('SQ_ACTIVE_INST_LDS') * 4 / simd_clk / 2:5.3f}  (the second and third were collected in another pass)")
+    print(f"  wave lifetime (clocks) {g('SQ_WAVE_CYCLES') * 4 / g('SQ_WAVES'):12.0f}   VALU instructions x 4 clk / wave lifetime {g('SQ_INSTS_VALU') * 4 / max(g('SQ_WAVE_CYCLES') * 4, 1):5.3f}")
     print(f"  per wave: VALU {g('SQ_INSTS_VALU') / g('SQ_WAVES'):9.0f}  SALU {g('SQ_INSTS_SALU') / g('SQ_WAVES'):9.0f}  VMEM rd {g('SQ_INSTS_VMEM_RD') / g('SQ_WAVES'):8.0f}"
           f"  VMEM wr {g('SQ_INSTS_VMEM_WR') / g('SQ_WAVES'):8.0f}  LDS {g('SQ_INSTS_LDS') / g('SQ_WAVES'):8.0f}")
     if g("TCC_REQ_sum"):

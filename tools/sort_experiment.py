@@ -11,16 +11,20 @@ if mode == "dump":
     os.environ["PTGPU_DUMP_LAUNCH"] = sys.argv[2] if len(sys.argv) > 2 else "12"
 import helpers as H
 from pathtracer_amd import scenes, image_io
-model = scenes.readme_standin(detail=1.0)
-env = image_io.load_hdr(os.path.join(root, "assets", "farmland_overcast_1k.hdr"))
+stress = os.environ.get("SCENE", "readme") == "stress"
+model = scenes.stress_mesh(10_000_000) if stress else scenes.readme_standin(detail=1.0)
+env = None if stress else image_io.load_hdr(os.path.join(root, "assets", "farmland_overcast_1k.hdr"))
+W, Hh = (3840, 2160) if stress else (800, 600)
 wide = os.environ.get("WIDE", "1") != "0"
-g = H.make_gpu(model, env, H.settings(program=2, spp=int(os.environ.get("SPP", "8")), bounces=6, newrays=0, wide=wide), 800, 600)
+g = H.make_gpu(model, env, H.settings(program=2, spp=int(os.environ.get("SPP", "8")), bounces=8 if stress else 6, newrays=0, wide=wide), W, Hh)
 if mode == "dump":
-    H.gpu_render(g, 800, 600)
+    H.gpu_render(g, W, Hh)
     print("dumped", os.path.getsize(path))
     sys.exit(0)
 raw = np.fromfile(path, dtype=np.float32).reshape(2, -1, 4)
-o = np.ascontiguousarray(raw[0, :, :3]); d = np.ascontiguousarray(raw[1, :, :3])
+limit = int(os.environ.get("MAX_RAYS", "0")) or raw.shape[1]
+o = np.ascontiguousarray(raw[0, :limit, :3]); d = np.ascontiguousarray(raw[1, :limit, :3])
+del raw
 n = o.shape[0]
 if mode == "sorted":
     lo = o.min(0); hi = o.max(0)
