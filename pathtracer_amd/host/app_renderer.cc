@@ -1,6 +1,8 @@
 // app_renderer.cc — Renderer / Viewer / loaders of the C++ host above the C ABI of libptgpu.
 #include "app_renderer.h"
 
+#include <thread>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -419,8 +421,38 @@ Renderer::Renderer(int device) {
         fail("ptgpu_create", rc);
     }
 }
+Renderer::Renderer(const std::vector<int>& devices, bool always_reduce) {
+    if (devices.empty()) throw std::runtime_error("Renderer: no devices");
+    for (int d : devices) {
+        ptgpu_ctx* c = nullptr;
+        const int rc = ptgpu_create(d, &c);
+        if (rc != PTGPU_OK) {
+            const std::string msg = ptgpu_last_error(nullptr);
+            for (ptgpu_ctx* made : ctxs_) ptgpu_destroy(made);
+            ctxs_.clear();
+            throw std::runtime_error("ptgpu_create failed (" + std::to_string(rc) + ") on device " + std::to_string(d) + ": " + msg);
+        }
+        ctxs_.push_back(c);
+    }
+    ctx_ = ctxs_[0];
+    if (devices.size() > 1 || always_reduce) {
+        try {
+            group_ = std::make_unique<DeviceGroup>(devices);
+        } catch (...) {
+            for (ptgpu_ctx* made : ctxs_) ptgpu_destroy(made);
+            ctxs_.clear();
+            ctx_ = nullptr;
+            throw;
+        }
+    }
+}
 Renderer::~Renderer() {
-    if (ctx_) ptgpu_destroy(ctx_);
+    group_.reset();
+    if (ctxs_.empty()) {
+        if (ctx_) ptgpu_destroy(ctx_);
+    } else {
+        for (ptgpu_ctx* c : ctxs_) ptgpu_destroy(c);
+    }
 }
 
 void Renderer::push_settings() {
@@ -438,8 +470,13 @@ void Renderer::push_settings() {
     s.flags = (single_path_ ? PTGPU_FLAG_SINGLE_PATH : 0u) | (wide_nodes_ ? PTGPU_FLAG_WIDE_NODES : 0u);
     s.tile_begin = 0;
     s.tile_step = 1;
-    const int rc = ptgpu_set_render_settings(ctx_, &s);
-    if (rc != PTGPU_OK) fail("ptgpu_set_render_settings", rc);
+    const size_t n = ctxs_.empty() ? 1 : ctxs_.size();
+    for (size_t k = 0; k < n; ++k) {
+        s.sample_begin = group_ ? static_cast<uint32_t>(k) : 0u;   // device k of n: samples k, k + n, ...
+        s.sample_step = group_ ? static_cast<uint32_t>(n) : 1u;
+        const int rc = ptgpu_set_render_settings(ctxs_.empty() ? ctx_ : ctxs_[k], &s);
+        if (rc != PTGPU_OK) fail("ptgpu_set_render_settings", rc);
+    }
 }
 void Renderer::set_render_settings(const RenderSettings& settings) {  // src/renderer.cc:67-75
     renderSettings_ = settings;
@@ -451,6 +488,11 @@ void Renderer::update_camera_transform_state(fvec3 position, fvec3 direction, fv
     const int rc = ptgpu_update_camera_transform_state(ctx_, &position.x, &direction.x, &up.x, p.yfov, p.aspectRatio.value_or(-1.0f),  // absent -> the reference defaults (src/renderer.cc:33-35)
                                                        p.znear, p.zfar.value_or(-1.0f));
     if (rc != PTGPU_OK) fail("ptgpu_update_camera_transform_state", rc);
+    for (size_t k = 1; k < ctxs_.size(); ++k) {  // the other devices get the very same matrices
+        float m[16], o[3];
+        if (ptgpu_get_camera_raw(ctx_, m, o) != PTGPU_OK || ptgpu_set_camera_raw(ctxs_[k], m, o) != PTGPU_OK)
+            throw std::runtime_error("camera state could not be copied to device context " + std::to_string(k));
+    }
 }
 
 void Renderer::load_scene(const Model& model, const CPUTexture<hdr_pixel>& envmap) {  // src/renderer.cc:41-65
@@ -511,13 +553,65 @@ void Renderer::load_scene(const Model& model, const CPUTexture<hdr_pixel>& envma
     m.images = images.data(); m.n_images = static_cast<uint32_t>(images.size());
     m.texels = reinterpret_cast<const uint8_t*>(texels.data()); m.n_texels = texels.size();
     ptgpu_envmap e{envmap.width(), envmap.height(), &envmap.data()->x};
-    const int rc = ptgpu_load_scene(ctx_, &m, &e);
-    if (rc != PTGPU_OK) fail("ptgpu_load_scene", rc);
+    if (ctxs_.size() <= 1) {
+        const int rc = ptgpu_load_scene(ctx_, &m, &e);
+        if (rc != PTGPU_OK) fail("ptgpu_load_scene", rc);
+        return;
+    }
+    // every device holds the whole scene (it is read-only and small next to 288 GB): one host thread per device
+    std::vector<int> rcs(ctxs_.size(), PTGPU_OK);
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < ctxs_.size(); ++k) workers.emplace_back([&, k] { rcs[k] = ptgpu_load_scene(ctxs_[k], &m, &e); });
+    for (std::thread& t : workers) t.join();
+    for (size_t k = 0; k < ctxs_.size(); ++k)
+        if (rcs[k] != PTGPU_OK)
+            throw std::runtime_error("ptgpu_load_scene failed (" + std::to_string(rcs[k]) + ") on device context " + std::to_string(k) + ": " +
+                                     ptgpu_last_error(ctxs_[k]));
 }
 
 void Renderer::render_frame(CPUFrameBuffer& framebuffer) {  // src/renderer.cc:77-123
+    if (group_) return render_frame_on_group(framebuffer);
     const int rc = ptgpu_render_frame(ctx_, framebuffer.width(), framebuffer.height(), framebuffer.raw(), &stats_);
     if (rc != PTGPU_OK) fail("render_frame", rc);
+}
+
+// The frame of src/renderer.cc:77-123 on several GPUs: the (pixel, sample) pairs are independent, so device k renders the
+// samples k, k + n, ... of every pixel into its own sum buffer; one RCCL reduce(sum) brings the partial sums to the first
+// device, which divides by the sample count.  The sub-pixel table and the sampler keys are indexed by the global sample
+// number, so the union over the devices is the sample set of a one-device frame.
+void Renderer::render_frame_on_group(CPUFrameBuffer& framebuffer) {
+    const int w = framebuffer.width(), h = framebuffer.height();
+    const size_t n_floats = static_cast<size_t>(w) * h * 4;
+    const size_t n = group_->size();
+    std::vector<float*> bufs(n);
+    for (size_t k = 0; k < n; ++k) bufs[k] = group_->sums(k, n_floats);
+    std::vector<int> rcs(n, PTGPU_OK);
+    std::vector<ptgpu_stats> stats(n);
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < n; ++k)
+        workers.emplace_back([&, k] { rcs[k] = ptgpu_render_frame_sums(ctxs_[k], w, h, bufs[k], group_->stream(k), &stats[k]); });
+    for (std::thread& t : workers) t.join();
+    for (size_t k = 0; k < n; ++k)
+        if (rcs[k] != PTGPU_OK)
+            throw std::runtime_error("render_frame failed (" + std::to_string(rcs[k]) + ") on device context " + std::to_string(k) + ": " +
+                                     ptgpu_last_error(ctxs_[k]));
+    group_->reduce_to_first(n_floats);
+    const uint32_t spp = renderSettings_.samplesPerPixel ? renderSettings_.samplesPerPixel : 1u;
+    const int rc = ptgpu_resolve_sums(ctx_, w, h, bufs[0], spp, group_->stream(0));
+    if (rc != PTGPU_OK) fail("ptgpu_resolve_sums", rc);
+    group_->download_first(framebuffer.raw(), n_floats);
+    stats_ = stats[0];
+    for (size_t k = 1; k < n; ++k) {  // counts add up, times are those of the slowest device
+        stats_.rays += stats[k].rays;
+        stats_.camera_samples += stats[k].camera_samples;
+        stats_.extend_launches += stats[k].extend_launches;
+        stats_.shade_launches += stats[k].shade_launches;
+        stats_.extend_ms = std::max(stats_.extend_ms, stats[k].extend_ms);
+        stats_.shade_ms = std::max(stats_.shade_ms, stats[k].shade_ms);
+        stats_.generate_ms = std::max(stats_.generate_ms, stats[k].generate_ms);
+        stats_.total_ms = std::max(stats_.total_ms, stats[k].total_ms);
+        stats_.traverse_ms = std::max(stats_.traverse_ms, stats[k].traverse_ms);
+    }
 }
 
 BBox Renderer::get_scene_bound() const {
@@ -539,6 +633,14 @@ std::vector<ptgpu_hit> Renderer::render_hits(int width, int height, uint32_t sam
 // ---------------------------------------------------------------------------------------------
 Viewer::Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device, bool wide_nodes)
     : model_(std::move(model)), environmentTexture_(std::move(environmentTexture)), renderer_(device) {
+    start(settings, wide_nodes);
+}
+Viewer::Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, const std::vector<int>& devices,
+               bool always_reduce, bool wide_nodes)
+    : model_(std::move(model)), environmentTexture_(std::move(environmentTexture)), renderer_(devices, always_reduce) {
+    start(settings, wide_nodes);
+}
+void Viewer::start(const RenderSettings& settings, bool wide_nodes) {
     if (!model_.cameras_.empty()) activeCameraIndex_ = 0;
     framebuffer_ = CPUFrameBuffer(windowDimensions_.x, windowDimensions_.y);
     renderer_.set_wide_nodes(wide_nodes);

@@ -8,10 +8,12 @@
 
 #include <cstdint>
 #include <filesystem>
+#include <memory>
 #include <optional>
 #include <vector>
 
 #include "app_model.h"
+#include "multi_gpu.h"
 #include "ptgpu.h"
 
 namespace app {
@@ -19,6 +21,11 @@ namespace app {
 class Renderer {
   public:
     explicit Renderer(int device = 0);
+    // Several GPUs of one node behind the one interface: every device holds the scene, renders its share of each
+    // pixel's samples (device k of n: samples k, k + n, ...), and the partial sums are added on the first device with an
+    // RCCL reduce before the mean is taken.  `always_reduce` sends a single device through the same path (a
+    // communicator of one).  Not in the reference, whose frame loop runs on one CPU.
+    Renderer(const std::vector<int>& devices, bool always_reduce);
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
     ~Renderer();
@@ -42,7 +49,10 @@ class Renderer {
     void push_settings();
     [[noreturn]] void fail(const char* what, int code) const;
 
-    ptgpu_ctx* ctx_ = nullptr;
+    void render_frame_on_group(CPUFrameBuffer& framebuffer);
+    ptgpu_ctx* ctx_ = nullptr;           // the first (or only) device's context
+    std::vector<ptgpu_ctx*> ctxs_;       // one per device, ctxs_[0] == ctx_
+    std::unique_ptr<DeviceGroup> group_; // set when frames go through the reduce
     RenderSettings renderSettings_;
     uint32_t seed_ = 0;
     bool single_path_ = false, wide_nodes_ = false;
@@ -53,6 +63,8 @@ class Viewer {  // src/viewer.h: owns model, environment, renderer and framebuff
   public:
     Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, int device = 0,
            bool wide_nodes = false);  // wide_nodes: Renderer::set_wide_nodes before the scene is loaded
+    Viewer(Model&& model, CPUTexture<hdr_pixel>&& environmentTexture, const RenderSettings& settings, const std::vector<int>& devices,
+           bool always_reduce, bool wide_nodes);  // several GPUs, see Renderer
     void resize_window(const ivec2& newDimensions);
     ivec2 get_window_dimensions() const { return windowDimensions_; }
     void render() { renderer_.render_frame(framebuffer_); }
@@ -66,6 +78,7 @@ class Viewer {  // src/viewer.h: owns model, environment, renderer and framebuff
     const CPUFrameBuffer& framebuffer() const { return framebuffer_; }
 
   private:
+    void start(const RenderSettings& settings, bool wide_nodes);
     void set_up_default_camera_transforms();
 
     Model model_;

@@ -1,6 +1,7 @@
 // PathTracer — command line of the reference (src/main.cc:12-62, src/arguments.cc:28-147) above the GPU renderer.
 // Same flags, defaults, stdout lines and exit codes; -f takes glTF 2.0 (.glb / .gltf) or the flat scene container.
-// Additive flags: --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw ptgpu_hit records,
+// Additive flags: --gpus N (sample split over N devices of this node + RCCL reduce), --collective (the reduce path even with
+// one device), --seed, --device, --dump-hits FILE (closest hit of sample 0 per pixel, raw ptgpu_hit records,
 // row-major), --stats, -a 3 (per-mesh trees built on the GPU), --wide-nodes (four-wide quantised nodes) and --single-path (PBR keeps one ray per hit, chosen in proportion to its payload).
 #include <chrono>
 #include <cstdio>
@@ -18,14 +19,15 @@ struct Args {
     std::string model, env = "white", output = "snapshot.hdr", dump_hits;
     int program = 3, as = 2, samples = 1, bounces = 4, newrays = 0, env_rot = 0, max_leaf = 8, width = 800, height = 600;
     unsigned seed = 0;
-    int device = 0;
-    bool stats = false, single_path = false, wide_nodes = false;
+    int device = 0, gpus = 1;
+    bool stats = false, single_path = false, wide_nodes = false, collective = false;
 };
 
 const char* kUsage =
     "Usage: PathTracer -f <scene.glb|.gltf|.ptsc> [-e <env.hdr>|black|white] [-o <out.png|out.hdr>] [-p 1|2|3] [-a 1|2|3]\n"
     "                  [-s samples] [-b bounces] [-r newrays] [--env_rot degrees] [-m max_leaf_triangles]\n"
-    "                  [--width W] [--height H] [--seed N] [--device N] [--dump-hits FILE] [--stats] [--single-path] [--wide-nodes]\n"
+    "                  [--width W] [--height H] [--seed N] [--device N] [--gpus N] [--collective]\n"
+    "                  [--dump-hits FILE] [--stats] [--single-path] [--wide-nodes]\n"
     "Use -h or --help for usage info.\n";
 
 bool parse(int argc, char** argv, Args& a) {
@@ -55,6 +57,8 @@ bool parse(int argc, char** argv, Args& a) {
         else if (k == "--width") { if (!num(a.width)) return false; }
         else if (k == "--height") { if (!num(a.height)) return false; }
         else if (k == "--device") { if (!num(a.device)) return false; }
+        else if (k == "--gpus") { if (!num(a.gpus)) return false; }
+        else if (k == "--collective") { a.collective = true; }
         else if (k == "--seed") { if (!(v = need(i))) return false; a.seed = static_cast<unsigned>(std::strtoul(v, nullptr, 10)); }
         else if (k == "--stats") { a.stats = true; }
         else if (k == "--single-path") { a.single_path = true; }
@@ -72,6 +76,7 @@ bool parse(int argc, char** argv, Args& a) {
     if (a.max_leaf < 1) a.max_leaf = 1;
     if (a.width < 1) a.width = 1;
     if (a.height < 1) a.height = 1;
+    if (a.gpus < 1) a.gpus = 1;
     if (a.model.empty()) {  // src/arguments.cc:136-139: the message, then exit code 1 (src/main.cc:18-20)
         std::cout << "A PathTracer for .gltf files on MI355X.\nUse -h or --help for usage info." << std::endl;
         return false;
@@ -115,7 +120,13 @@ int main(int argc, char* argv[]) {
         settings.programMode = static_cast<RayProgramMode>(args.program - 1);
         settings.accelStructType = static_cast<AccelerationStructureType>(args.as - 1);
 
-        Viewer viewer(std::move(model), std::move(environment_texture), settings, args.device, args.wide_nodes);
+        // --gpus N: devices --device, --device + 1, ...; each renders its share of every pixel's samples, the partial sums
+        // are reduced onto the first one over RCCL (--collective: also with one device, a communicator of one)
+        std::vector<int> devices;
+        for (int g = 0; g < args.gpus; ++g) devices.push_back(args.device + g);
+        const bool grouped = args.gpus > 1 || args.collective;
+        Viewer viewer = grouped ? Viewer(std::move(model), std::move(environment_texture), settings, devices, args.collective, args.wide_nodes)
+                                : Viewer(std::move(model), std::move(environment_texture), settings, args.device, args.wide_nodes);
         viewer.renderer().set_seed(args.seed);
         viewer.renderer().set_single_path(args.single_path);
         viewer.resize_window(ivec2{args.width, args.height});

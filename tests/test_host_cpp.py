@@ -139,6 +139,38 @@ def test_cli_repairs_out_of_range_values_like_the_reference(tmp_path):
 
 @needs_cli
 @pytest.mark.gpu
+def test_cli_multi_gpu_path_with_a_communicator_of_one(tmp_path):
+    """--gpus N splits every pixel's samples over N devices and adds the partial sums with an RCCL reduce.  A box with one
+    GPU can still run the whole path — contexts, per-device sum buffer and stream, ncclCommInitAll, ncclReduce, the
+    division on the first device — with one device (--collective); the frame must be the plain one up to the order of
+    the float additions.  More devices than the node has is an error, not a silent fallback."""
+    import torch
+    scene = tmp_path / "tiny.ptsc"
+    scenes.tiny_scene().save(str(scene))
+    w, h = 64, 40
+    common = ["-f", scene, "-p", 3, "-a", 2, "-s", 6, "-b", 3, "--width", w, "--height", h, "--seed", 11, "--stats"]
+    a, b = tmp_path / "plain.hdr", tmp_path / "reduced.hdr"
+    r1 = run(*common, "-o", a)
+    assert r1.returncode == 0, r1.stderr
+    r2 = run(*common, "--gpus", 1, "--collective", "-o", b)
+    assert r2.returncode == 0, r2.stderr
+    rays = [ln.split()[1] for ln in (r1.stdout + r2.stdout).splitlines() if ln.startswith("rays ")]
+    assert len(rays) == 2 and rays[0] == rays[1]
+    x, y = image_io.load_hdr(str(a))[..., :3], image_io.load_hdr(str(b))[..., :3]
+    scale = np.maximum(x.max(axis=-1, keepdims=True), 1e-6)
+    assert (np.abs(x - y) <= scale / 100.0).all()      # RGBE keeps 8 bits of the largest channel
+    n = torch.cuda.device_count()
+    r3 = run(*common, "--gpus", n + 1, "-o", b)
+    assert r3.returncode == 1 and "device index out of range" in r3.stderr
+    if n >= 2:   # a node with several GPUs: the real split
+        r4 = run(*common, "--gpus", 2, "-o", b)
+        assert r4.returncode == 0, r4.stderr
+        y = image_io.load_hdr(str(b))[..., :3]
+        assert (np.abs(x - y) <= scale / 100.0).all()
+
+
+@needs_cli
+@pytest.mark.gpu
 def test_cli_renders_glb_like_the_scene_container(tmp_path):
     """-f scene.glb goes through the C++ glTF reader; the same scene as a flat container must give the same picture
     (normal matrices are recomputed in binary32 by the reader, hence a tolerance instead of equality)."""
