@@ -83,6 +83,32 @@ def test_config1_raycast_640x360_bit_exact(golden):
     assert digest(img) == str(golden["c1_image_digest"][0])
 
 
+def test_config1_full_detail_scene_against_live_oracle():
+    """BASELINE configuration 1 on the scene the benchmark renders (the ~1.24 M-triangle stand-in, not a reduced one):
+    raycast, BVH, 640x360, 1 spp, white environment — every pixel's hit record against an oracle run made here, and the
+    raycast image (albedo / environment colour) against the oracle's.  Requirement: triangle ids identical on >= 99.99 %
+    of the pixels, depth within 1e-5 relative; both node layouts."""
+    model = scenes.readme_standin(detail=1.0)
+    w, h = 640, 360
+    o = H.make_oracle(model, None, H.settings(program=0), w, h)
+    ref = o.render_hits(w, h)
+    ref_img, _ = o.render_frame(w, h)
+    assert ref["hit"].mean() > 0.5
+    for wide in (False, True):
+        g = H.make_gpu(model, None, H.settings(program=0, wide=wide), w, h)
+        hits = g.render_hits(w, h)
+        exact, ids = H.hits_equal(ref, hits)
+        assert ids.mean() >= 0.9999, f"wide={wide}: ids differ on {(~ids).sum()} pixels"
+        both = (ref["hit"] == 1) & (hits["hit"] == 1)
+        rel = np.abs(ref["t"][both] - hits["t"][both]) / ref["t"][both]
+        assert rel.max() <= 1e-5
+        if not wide:
+            assert exact.all(), f"{(~exact).sum()} records are not bit-identical"   # the reference's visiting order: every bit
+        img, st = H.gpu_render(g, w, h)
+        assert st.rays == w * h
+        assert (np.abs(img[..., :3] - ref_img[..., :3]) <= 2e-5).mean() >= 0.9999
+
+
 @pytest.mark.parametrize("as_type", [0, 1])
 def test_intersect_rays_closest_and_any_hit(as_type):
     """IAccelerationStructure::intersect_ray on arbitrary rays, both traversal kinds, both AS types."""

@@ -149,6 +149,36 @@ def test_portable_math_close_to_libm(golden):
     assert np.abs(e[:, 0] - e[:, 1]).max() < 1e-3 * max(1.0, np.abs(e).max())
 
 
+def test_portable_environment_coordinates_close_to_libm():
+    """sample_environment (brdf.cc:62-69) with the polynomial atan2 / asin shared with the GPU against the same function
+    with libm, on the lookup coordinates themselves: the environment is a ramp (red = (x + 0.5) / width, green =
+    (y + 0.5) / height), which bilinear filtering reproduces exactly, so the sampled colour IS (u, v) away from the wrap
+    seam.  Bound 5e-7 = 4 binary32 ulps of a coordinate near 1 (measured: 99 % of directions within 1.2e-7)."""
+    w, h = 256, 128
+    env = np.zeros((h, w, 4), np.float32)
+    env[..., 0] = ((np.arange(w) + 0.5) / w)[None, :]
+    env[..., 1] = ((np.arange(h) + 0.5) / h)[:, None]
+    rng = np.random.default_rng(3)
+    d = rng.normal(size=(4000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    fp = ob.abi.c_float_p
+    out = np.zeros((2, len(d), 4), np.float32)
+    for mode in (ob.MATH_LIBM, ob.MATH_PORTABLE):
+        for i in range(len(d)):
+            ob.lib().orc_kat_sample_environment(env.ctypes.data_as(fp), w, h, d[i].ctypes.data_as(fp), np.float32(0.0), mode,
+                                                out[mode, i].ctypes.data_as(fp))
+    angle = np.arctan2(-d[:, 2].astype(np.float64), -d[:, 0].astype(np.float64))
+    away = (np.abs(angle) < np.pi - 0.05) & (np.abs(angle) > 0.05) & (np.abs(d[:, 1]) < 0.99)   # not at the seam, not at a pole
+    assert away.mean() > 0.8
+    assert np.abs(out[0, away, 0] - out[1, away, 0]).max() < 5e-7
+    assert np.abs(out[0, away, 1] - out[1, away, 1]).max() < 5e-7
+    # and the ramp does reproduce the coordinate: u of the libm evaluation against the formula in double precision
+    u = (angle / np.pi) * 0.5 + 0.5
+    got = out[0, :, 0].astype(np.float64)
+    du = np.abs(got - u)
+    assert np.minimum(du, np.abs(du - 1.0))[away].max() < 2e-6
+
+
 def test_sums_and_mean_agree():
     model = scenes.tiny_scene()
     env = scenes.synthetic_env()
