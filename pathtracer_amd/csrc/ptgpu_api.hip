@@ -894,6 +894,69 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         std::vector<uint32_t> mesh_root4(model->n_meshes, PT_NO_NODE);
         std::vector<uint32_t> binary_root(model->n_meshes, PT_NO_NODE);
         for (const ptd::DevXform& xf : table.xforms) binary_root[xf.mesh_index] = xf.root;
+        // Which binary nodes survive as four-wide nodes.  A ray pays one visit per surviving node whose box it enters, so
+        // the expected number of visits is the summed surface area of the surviving nodes; that sum is minimised exactly by
+        // dynamic programming over the binary tree (Ylitie, Karras, Laine: Efficient incoherent ray traversal on GPUs
+        // through compressed wide BVHs, 2017, section 4.1): cost[n][k] = least area below n when n's subtree is
+        // represented by at most k+1 roots (k = 0: n itself is a wide node), part[n][k] = how many of them its left child gets
+        // (0 = the solution for one root fewer is as good).  PTGPU_WIDE_COLLAPSE=greedy selects the older rule instead
+        // (always pull up the child with the largest box).
+        const char* collapse_env = std::getenv("PTGPU_WIDE_COLLAPSE");
+        const bool optimal_collapse = !(collapse_env && !std::strcmp(collapse_env, "greedy"));
+        std::vector<float> cost;
+        std::vector<uint8_t> part;
+        auto cost_of = [&](uint32_t ref, int roots) { return (ref & PT_LEAF_BIT) ? 0.0f : cost[static_cast<size_t>(ref) * 4 + (roots - 1)]; };
+        if (optimal_collapse) {
+            cost.assign(all_nodes.size() * 4, 0.0f);
+            part.assign(all_nodes.size() * 4, 0);
+            std::vector<uint32_t> order;  // every node after its children: reverse of a pre-order walk
+            for (uint32_t m = 0; m < model->n_meshes; ++m) {
+                if (binary_root[m] == PT_NO_NODE || (binary_root[m] & PT_LEAF_BIT)) continue;
+                const size_t first = order.size();
+                order.push_back(binary_root[m]);
+                for (size_t i = first; i < order.size(); ++i) {
+                    const ptd::DevNode& nd = all_nodes[order[i]];
+                    if (!(nd.left & PT_LEAF_BIT)) order.push_back(nd.left);
+                    if (!(nd.right & PT_LEAF_BIT)) order.push_back(nd.right);
+                }
+            }
+            for (size_t i = order.size(); i-- > 0;) {
+                const uint32_t n = order[i];
+                const ptd::DevNode& nd = all_nodes[n];
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; ++a) {
+                    lo[a] = std::min(nd.l_lo[a], nd.r_lo[a]);
+                    hi[a] = std::max(nd.l_hi[a], nd.r_hi[a]);
+                }
+                const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+                const float own = dx * dy + dx * dz + dy * dz;
+                float below[5] = {0, 0, 0, 0, 0};  // below[k]: children represented by at most k roots, k = 2..4
+                uint8_t left_share[5] = {0, 0, 0, 0, 0};
+                for (int k = 2; k <= 4; ++k) {
+                    below[k] = std::numeric_limits<float>::infinity();
+                    for (int l = 1; l < k; ++l) {
+                        const float c = cost_of(nd.left, l) + cost_of(nd.right, k - l);
+                        if (c < below[k]) {
+                            below[k] = c;
+                            left_share[k] = static_cast<uint8_t>(l);
+                        }
+                    }
+                }
+                float* c = &cost[static_cast<size_t>(n) * 4];
+                uint8_t* p4 = &part[static_cast<size_t>(n) * 4];
+                c[0] = own + below[4];       // one root: n is a wide node, its (at most four) children come from below[4]
+                p4[0] = left_share[4];
+                for (int k = 2; k <= 4; ++k) {  // k roots: n dissolves into its children's roots, unless k - 1 roots do as well
+                    if (c[k - 2] <= below[k]) {
+                        c[k - 1] = c[k - 2];
+                        p4[k - 1] = 0;
+                    } else {
+                        c[k - 1] = below[k];
+                        p4[k - 1] = left_share[k];
+                    }
+                }
+            }
+        }
         for (uint32_t m = 0; m < model->n_meshes; ++m) {
             const uint32_t root = binary_root[m];
             if (root == PT_NO_NODE) continue;  // mesh without an instance
@@ -908,7 +971,37 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
                 Child ch[4];
                 int n_ch = 2;
                 children_of(t.binary, ch);
-                while (n_ch < 4) {  // pull up the inner child with the largest box
+                if (optimal_collapse) {
+                    // follow the recorded decisions: `roots` of the subtree below a child become children of this wide node
+                    n_ch = 0;
+                    struct Open {
+                        Child c;
+                        int roots;
+                    };
+                    Open open[8];
+                    int n_open = 0;
+                    Child two[2];
+                    children_of(t.binary, two);
+                    const int l = part[static_cast<size_t>(t.binary) * 4];
+                    open[n_open++] = {two[1], 4 - l};
+                    open[n_open++] = {two[0], l};
+                    while (n_open) {
+                        const Open o = open[--n_open];
+                        if ((o.c.ref & PT_LEAF_BIT) || o.roots == 1) {
+                            ch[n_ch++] = o.c;
+                            continue;
+                        }
+                        const int share = part[static_cast<size_t>(o.c.ref) * 4 + (o.roots - 1)];
+                        if (share == 0) {
+                            open[n_open++] = {o.c, o.roots - 1};
+                            continue;
+                        }
+                        children_of(o.c.ref, two);
+                        open[n_open++] = {two[1], o.roots - share};
+                        open[n_open++] = {two[0], share};
+                    }
+                }
+                while (!optimal_collapse && n_ch < 4) {  // pull up the inner child with the largest box
                     int best = -1;
                     float best_area = -1.0f;
                     for (int k = 0; k < n_ch; ++k)
