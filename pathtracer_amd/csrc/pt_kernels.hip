@@ -655,9 +655,12 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     const float fy = __builtin_fmaf(static_cast<float>((fqy >> sh) & 0xffu), by, ay);
                     const float nz = __builtin_fmaf(static_cast<float>((nqz >> sh) & 0xffu), bz, az);
                     const float fz = __builtin_fmaf(static_cast<float>((fqz >> sh) & 0xffu), bz, az);
-                    const float t0 = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-                    const float t1 = __builtin_fminf(__builtin_fminf(fx, fy), fz);
-                    return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
+                    // The interval of the box is cut to [0, current hit distance] before it is tested for being empty: one
+                    // comparison decides "entered, in front, and nearer than the hit".  (A box entered exactly at the hit
+                    // distance, or touched exactly at the origin, counts as entered here: a visit more, never a hit less.)
+                    const float t0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(nx, ny), nz), 0.0f);
+                    const float t1 = __builtin_fminf(__builtin_fminf(__builtin_fminf(fx, fy), fz), h_t);
+                    return (t0 <= t1) ? t0 : kInfF;
                 };
                 d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
             } else {  // an infinite inverse direction: planes decoded, exact select forms
@@ -669,16 +672,13 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                              q0.z + q1.y * static_cast<float>((lqz >> sh) & 0xffu), q0.x + q0.w * static_cast<float>((hqx >> sh) & 0xffu),
                              q0.y + q1.x * static_cast<float>((hqy >> sh) & 0xffu), q0.z + q1.y * static_cast<float>((hqz >> sh) & 0xffu),
                              o, inv, hh, dd);
-                    return dd;
+                    return (h_t > dd) ? dd : kInfF;  // a candidate when its box is entered nearer than the current hit
                 };
                 d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
             }
+            // (a node with fewer than four children has its unused slots filled with an inverted box around a leaf that holds
+            // one degenerate triangle, so no slot needs an "exists" test: see the conversion in ptgpu_load_scene)
             uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
-            // a child is a candidate when it exists and its box is entered nearer than the current hit
-            d0 = (r0 != PT_NO_NODE && h_t > d0) ? d0 : kInfF;
-            d1 = (r1 != PT_NO_NODE && h_t > d1) ? d1 : kInfF;
-            d2 = (r2 != PT_NO_NODE && h_t > d2) ? d2 : kInfF;
-            d3 = (r3 != PT_NO_NODE && h_t > d3) ? d3 : kInfF;
             auto order = [](float& da, uint32_t& ra, float& db, uint32_t& rb) {
                 const bool swap = db < da;
                 const float dn = swap ? db : da, df = swap ? da : db;

@@ -1044,8 +1044,18 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
                         nd.qhi[a] |= static_cast<uint32_t>(qh) << (8 * k);
                     }
                 }
+                // An unused slot is not marked "absent": it names the padding record after the last triangle (one degenerate
+                // triangle, never hit) as a leaf, inside an inverted box (low planes 255, high planes 0) that no ray enters —
+                // except in a node of zero extent, where the degenerate triangle is tested and missed.  The kernel so needs no
+                // test for a slot's existence.
+                const uint32_t dummy_leaf = PT_LEAF_BIT | static_cast<uint32_t>(all_tris.size());
+                for (int k = n_ch; k < 4; ++k)
+                    for (int a = 0; a < 3; ++a) {
+                        nd.qlo[a] |= 255u << (8 * k);
+                        nd.qhi[a] &= ~(255u << (8 * k));
+                    }
                 for (int k = 0; k < 4; ++k)
-                    nd.ref[k] = (k >= n_ch) ? PT_NO_NODE
+                    nd.ref[k] = (k >= n_ch) ? dummy_leaf
                                             : ((ch[k].ref & PT_LEAF_BIT) ? ch[k].ref : make(ch[k].ref, depth_of[t.wide_index] + 1));
                 wide[t.wide_index] = nd;
             }
@@ -1194,9 +1204,13 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         q.right = n.right;
         q.pad0 = q.pad1 = 0;
     }
-    std::vector<ptd::TriQ> q_tris(all_tris.size() + 1);  // + one record of padding: the four-wide kernel reads triangles in pairs
-    std::memset(&q_tris.back(), 0, sizeof(ptd::TriQ));
-    q_tris.back().leaf_count = 1;
+    // + two records of padding: the four-wide kernel reads triangles in pairs, and the first padding record is itself a leaf
+    // (one degenerate triangle: the filler of unused child slots)
+    std::vector<ptd::TriQ> q_tris(all_tris.size() + 2);
+    for (size_t k = all_tris.size(); k < q_tris.size(); ++k) {
+        std::memset(&q_tris[k], 0, sizeof(ptd::TriQ));
+        q_tris[k].leaf_count = 1;
+    }
     uint32_t in_leaf = 0;  // the builder marks a leaf's first triangle with the leaf size; every triangle gets the rest count
     for (size_t i = 0; i < all_tris.size(); ++i) {
         const ptd::DevTri& t = all_tris[i];
