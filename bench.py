@@ -200,6 +200,7 @@ def main() -> None:
     work_stream = torch.cuda.Stream()
     stream = work_stream.cuda_stream
     assert stream != 0
+    torch.cuda.synchronize()  # the buffer's zero fill ran on torch's default stream, which this stream does not wait for
 
     def step():
         with torch.cuda.stream(work_stream):
