@@ -296,7 +296,13 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
-    const uint64_t cap_limit = (32ull << 30) / 48;  // at most 32 GiB per pool; the scheduler splits segments beyond that
+    // at most 32 GiB per pool (PTGPU_POOL_GIB overrides); the scheduler splits segments beyond that
+    static const uint64_t pool_gib = [] {
+        const char* v = std::getenv("PTGPU_POOL_GIB");
+        const long g = v ? std::atol(v) : 0;
+        return static_cast<uint64_t>(g >= 1 ? g : 32);
+    }();
+    const uint64_t cap_limit = (pool_gib << 30) / 48;
     cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
     // A failed allocation leaves its buffer empty (ensure frees first).  The sizes recorded in the context must never
     // claim more than the buffers hold, so they are cleared before anything is touched and set again once all of it is there.
