@@ -481,6 +481,31 @@ def test_edge_cases():
         assert np.allclose(H.gpu_render(g, w, h)[0], o.render_frame(w, h)[0], rtol=1e-5, atol=1e-6)
 
 
+def test_settings_corner_values(tiny):
+    """maxRayBounces goes through a uint8 cast (renderer.cc:73): 256 bounces are 0, 257 are 1.  The default -r 0 of the
+    ambient-occlusion program spawns no rays at all (aoSamples = 0, ray_program.cc:167): a hit contributes nothing, a miss
+    the payload.  A sample count that is no square takes the Fibonacci sub-pixel table (renderer.cc:148-153)."""
+    model, env = tiny
+    w, h = 40, 24
+    for big, small in ((256, 0), (257, 1)):
+        a = H.make_gpu(model, env, H.settings(program=2, spp=3, bounces=big), w, h)
+        b = H.make_gpu(model, env, H.settings(program=2, spp=3, bounces=small), w, h)
+        ia, sa = H.gpu_render(a, w, h)
+        ib, sb = H.gpu_render(b, w, h)
+        assert sa.rays == sb.rays and np.abs(ia - ib).max() <= 2e-5 * max(1.0, float(ib.max()))
+        o = H.make_oracle(model, env, H.settings(program=2, spp=3, bounces=big), w, h)
+        io, so = o.render_frame(w, h)
+        assert so.rays == sa.rays and np.abs(ia[..., :3] - io[..., :3]).max() <= 2e-5 * max(1.0, float(io.max()))
+    st = H.settings(program=1, spp=5, bounces=1, newrays=0)   # 5 samples: Fibonacci table
+    g, o = H.make_gpu(model, None, st, w, h), H.make_oracle(model, None, st, w, h)
+    img, s = H.gpu_render(g, w, h)
+    ref, so = o.render_frame(w, h)
+    assert s.rays == so.rays == w * h * 5
+    assert np.abs(img[..., :3] - ref[..., :3]).max() <= 2e-6
+    hit = o.render_hits(w, h)["hit"]
+    assert (img[..., 0][hit == 0] > 0.0).all()
+
+
 def test_error_behaviour(tiny):
     model, env = tiny
     r = Renderer(0)
