@@ -773,10 +773,8 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     }
                 }
                 if (enter_slot == PT_NO_NODE) {  // the ray is done here
-                    if (!(flags & F_BHIT)) {
-                        hit0[rid] = make_float4(kInfF, 0.0f, 0.0f, 0.0f);
-                        hit1[rid] = 0u;
-                    }
+                    // a miss is one word: nothing reads the distance / barycentrics record of a ray whose flag word says "no hit"
+                    if (!(flags & F_BHIT)) hit1[rid] = 0u;
                     if (deferred) overflow[1u + atomicAdd(overflow, 1u)] = rid;
                     cur = PT_IDLE;
                 }
@@ -1366,12 +1364,12 @@ __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQ
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 ro = rays.o[i], rd = rays.d[i];
-    const float4 h0 = hits.h0[i];
     const uint32_t h1 = hits.h1[i];
     f3 c;
     if (!(h1 & 0x80000000u)) {
         c = sample_environment(sc, ld3(rd));
     } else {
+        const float4 h0 = hits.h0[i];  // written for hits only
         const uint32_t object = h1 & 0x3fffffffu;
         const DevObject* obj = object_record(sc, object);
         const float4* rec = sc.corners + static_cast<size_t>(obj->tri_base + __float_as_uint(h0.w) / 3u) * 9u;
@@ -1399,7 +1397,6 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
     uint32_t pid = 0, key = 0, new_depth = 0;
     if (i < n) {
         const float4 ro = rays.o[i], rd = rays.d[i], rp = rays.p[i];
-        const float4 h0 = hits.h0[i];
         const uint32_t h1 = hits.h1[i];
         pid = __float_as_uint(ro.w);
         key = __float_as_uint(rp.w);
@@ -1407,6 +1404,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
         if (!(h1 & 0x80000000u)) {
             add_radiance(fb, pid, f3{rp.x, rp.y, rp.z});  // miss: return the payload
         } else if (depth != 0) {
+            const float4 h0 = hits.h0[i];  // written for hits only
             ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             normals_to_world(sp);
             const DevMaterial& mat = sp.obj->mat;
@@ -1498,7 +1496,6 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     if (i < n) {
         rd = rays.d[i];
         const float4 rp = rays.p[i];
-        const float4 h0 = hits.h0[i];
         const uint32_t h1 = hits.h1[i];
         // the framebuffer slot rides in the direction record's flag word when it fits (uniform choice per frame)
         const uint32_t pid = (fb.stride < (1u << 23)) ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
@@ -1512,6 +1509,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             radiance = payload * sample_environment(sc, dir);
         } else {
             const bool backface = (h1 & 0x40000000u) != 0;
+            const float4 h0 = hits.h0[i];  // written for hits only
             ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             sp.p.position = xform(sp.obj->model, sp.p.position, 1.0f);
             normals_to_world(sp);
