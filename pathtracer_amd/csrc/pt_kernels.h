@@ -33,12 +33,14 @@ struct HitQueue {
     uint32_t* h1;
 };
 
-// Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot);
-// a slot of PT_NO_NODE ends the list; at most kCandMax entries are stored (longer lists are continued by a rescan).
+// Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot).  The slot word
+// of the last stored entry carries kCandLast unless the list is full (kCandMax entries: it may go on, a rescan continues it);
+// a ray without candidates has the one entry (-, PT_NO_NODE).
 #ifndef PT_CAND_MAX
 #define PT_CAND_MAX 8
 #endif
 constexpr int kCandMax = PT_CAND_MAX;
+constexpr uint32_t kCandLast = 0x40000000u;  // instance slots are below 2^30
 #ifndef PT_TLAS_LINEAR_MAX
 #define PT_TLAS_LINEAR_MAX 96
 #endif

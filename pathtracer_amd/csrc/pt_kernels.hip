@@ -443,10 +443,15 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
         }
         ++wave_filled;
     }
+    // An entry's slot word carries kCandLast when the stored list ends with it, so a list costs no terminator entry and
+    // the traversal kernel knows without a read that nothing follows; an empty list is one entry with the slot PT_NO_NODE.
 #pragma unroll
     for (int j = 0; j < kCandMax; ++j)
-        if (j == 0 || slot[j - 1] != PT_NO_NODE)
-            cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j]);
+        if (j == 0 || slot[j] != PT_NO_NODE) {
+            const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
+            cand.e[static_cast<size_t>(j) * cand.stride + gid] =
+                make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j] | (last ? kCandLast : 0u));
+        }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
 }
 
@@ -531,10 +536,15 @@ __global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const fl
             }
         }
     }
+    // An entry's slot word carries kCandLast when the stored list ends with it, so a list costs no terminator entry and
+    // the traversal kernel knows without a read that nothing follows; an empty list is one entry with the slot PT_NO_NODE.
 #pragma unroll
     for (int j = 0; j < kCandMax; ++j)
-        if (j == 0 || slot[j - 1] != PT_NO_NODE)
-            cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j]);
+        if (j == 0 || slot[j] != PT_NO_NODE) {
+            const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
+            cand.e[static_cast<size_t>(j) * cand.stride + gid] =
+                make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j] | (last ? kCandLast : 0u));
+        }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(tested));
 }
 
@@ -567,7 +577,7 @@ __device__ __forceinline__ float box_entry_fast(float lox, float loy, float loz,
     return ((t0 <= t1) && (t1 > 0.0f)) ? __builtin_fmaxf(t0, 0.0f) : kInfF;
 }
 
-enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u };
+enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u, F_LAST = 16u };  // F_LAST: the candidate list has no further entry
 template <bool COUNT, bool WIDE>
 __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                  const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
@@ -743,7 +753,16 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             uint32_t enter_slot = PT_NO_NODE;
             f3 ow = mk3(0.0f), dw = mk3(0.0f);
             auto pick = [&](bool fresh) {
-                const float4 ro = ray_o[rid], rd = ray_d[rid];
+                // A ray that has consumed the last entry of its candidate list needs neither its direction nor another
+                // list entry, and its origin only to turn a hit's distance into world space.
+                const bool more = fresh || !(flags & F_LAST);
+                float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro;
+                if (more) {
+                    ro = ray_o[rid];
+                    rd = ray_d[rid];
+                } else if (h_hit) {
+                    ro = ray_o[rid];
+                }
                 ow = ld3(ro);
                 dw = ld3(rd);
                 if (fresh) {
@@ -763,11 +782,14 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                 }
                 const bool any_hit = (flags & F_ANY) != 0;
                 bool deferred = false;
-                if (!(any_hit && (flags & F_BHIT))) {
+                if (more && !(any_hit && (flags & F_BHIT))) {
                     if (cursor < kCandMax) {
                         const uint2 e = cand.e[static_cast<size_t>(cursor) * cand.stride + rid];
                         ++cursor;
-                        if (e.y != PT_NO_NODE && (any_hit || (__uint_as_float(e.x) < b_t))) enter_slot = e.y;
+                        if (e.y != PT_NO_NODE) {
+                            if (e.y & kCandLast) flags |= F_LAST;
+                            if (any_hit || (__uint_as_float(e.x) < b_t)) enter_slot = e.y & ~kCandLast;
+                        }
                     } else {
                         deferred = true;  // all stored candidates are used up: the continuation pass takes the ray
                     }
@@ -995,6 +1017,7 @@ __global__ __launch_bounds__(kBlock) void extend_overflow_kernel(SceneDev sc, co
         best.object = h1 & 0x3fffffffu;
         best.backface = (h1 & 0x40000000u) != 0;
         uint2 last = cand.e[static_cast<size_t>(kCandMax - 1) * cand.stride + rid];
+        last.y &= ~kCandLast;
         for (;;) {
             const uint2 e = tlas_rescan(sc, o, d, any_hit, __uint_as_float(last.x), last.y);
             if (e.y == PT_NO_NODE) break;
