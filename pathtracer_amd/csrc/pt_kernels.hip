@@ -1508,21 +1508,26 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     const uint32_t i = blockIdx.x * kShadeBlock + threadIdx.x;
     bool has[4] = {false, false, false, false};  // pass-through, diffuse, transmission, reflection
     // state that survives from stage A to stage C
-    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro;
-    f3 payload = mk3(0.0f), position = mk3(0.0f), normal = mk3(0.0f), atten = mk3(1.0f), v = mk3(0.0f), m = mk3(0.0f), l_refr = mk3(0.0f);
-    f3 diffuse_color = mk3(0.0f), f0 = mk3(0.0f);
-    Tbn tbn{mk3(0.0f), mk3(0.0f), mk3(0.0f)};
-    float alpha = 0.0f, transmission = 0.0f, a_lin = 0.0f, eta = 1.0f, u0 = 0.0f, u1 = 0.0f;
-    uint32_t key = 0, nflags = 0;
+    const float4 ro = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 rd = ro;
+    // (the view vector and the refracted direction are cheap to form again in stage C; the diffuse direction is formed
+    // in stage A, so that the tangent and bitangent need not survive)
+    f3 payload = mk3(0.0f), position = mk3(0.0f), normal = mk3(0.0f), atten = mk3(1.0f), m = mk3(0.0f), l_diff = mk3(0.0f);
+    f3 diffuse_color = mk3(0.0f), f0 = mk3(0.0f), shading_n = mk3(0.0f);
+    float alpha = 0.0f, transmission = 0.0f, a_lin = 0.0f, eta = 1.0f;
+    uint32_t key = 0;
     bool exiting = false;
 
+    // the framebuffer slot rides in the direction record's flag word when it fits (uniform choice per frame); asked for
+    // again in stage C instead of being kept in a register
+    auto slot_of = [&]() -> uint32_t {
+        return (fb.stride < (1u << 23)) ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
+    };
     if (i < n) {
         rd = rays.d[i];
         const float4 rp = rays.p[i];
         const uint32_t h1 = hits.h1[i];
-        // the framebuffer slot rides in the direction record's flag word when it fits (uniform choice per frame)
-        const uint32_t pid = (fb.stride < (1u << 23)) ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
-        ro.w = __uint_as_float(pid);
+        const uint32_t pid = slot_of();
         key = __float_as_uint(rp.w);
         const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
         payload = f3{rp.x, rp.y, rp.z};
@@ -1555,10 +1560,10 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                 const f3 emissive = sample_emissive(sc, mat, sp.p.u, sp.p.v);
                 radiance = payload * emissive * atten * alpha;
                 if (depth != 0) {
-                    v = -dir;
+                    const f3 v = -dir;
                     const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
                     // handle_TBN_creation (ray_program.cc:121-142)
-                    tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
+                    Tbn tbn = make_tbn(f3{sp.p.tangent.x, sp.p.tangent.y, sp.p.tangent.z}, sp.bitangent, sp.p.normal);
                     const bool has_map = (nm.w != 0.0f);
                     f3 nv = has_map ? normal_map_to_world(nm, tbn) : tbn.n;
                     const bool impossible = dot3(exiting ? -v : v, nv) < 0.0f;
@@ -1575,16 +1580,16 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                     diffuse_color = (1.0f - orm.z) * alb;
                     f0 = mix3(mk3(mat.f0), alb, orm.z);
                     a_lin = orm.y * orm.y;
-                    nflags = ((depth - 1u) & 0xffu) | (pid << 9);
-                    u0 = rng_uniform(key, 0);
-                    u1 = rng_uniform(key, 1);
+                    const float u0 = rng_uniform(key, 0), u1 = rng_uniform(key, 1);
                     const float u2 = rng_uniform(key, 2), u3 = rng_uniform(key, 3);
                     // micro-normal shared by transmission and reflection (:324-389)
                     m = mul_tbn(tbn.t, tbn.b, tbn.n, ggx_dir(u2, u3, a_lin));
                     if (exiting) m = m * -1.0f;
                     eta = (!exiting) ? 1.0f / mat.ior : mat.ior;
-                    l_refr = refract3(-v, m, eta);
+                    const f3 l_refr = refract3(-v, m, eta);
+                    shading_n = tbn.n;
                     has[1] = any_ne(diffuse_color * (1.0f - transmission), mk3(0.0f));
+                    if (has[1]) l_diff = normalize3(mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(u0, u1)));
                     has[2] = any_ne(diffuse_color * transmission, mk3(0.0f)) && any_ne(l_refr, mk3(0.0f));
                     has[3] = true;
                 }
@@ -1596,7 +1601,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     const uint32_t lane_id = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane_id) - 1ull;
     auto store = [&](uint32_t dst, f3 org, float4 d4, f3 pl, uint32_t lobe) {
-        out.o[dst] = make_float4(org.x, org.y, org.z, ro.w);
+        out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of()));
         out.d[dst] = d4;
         out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
     };
@@ -1605,15 +1610,18 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     if (has[0]) emit(std::integral_constant<int, 0>{}, position + (exiting ? 1.0f : -1.0f) * normal * 1e-5f, rd, payload * (1.0f - alpha), LOBE_PASS);
     if (has[3]) {  // every lane that reaches the lobes has the reflection lobe
         const f3 f90 = mk3(1.0f);
+        const f3 v = -ld3(rd);
+        const f3 l_refr = refract3(-v, m, eta);
+        const uint32_t nflags = (((__float_as_uint(rd.w) & 0xffu) - 1u) & 0xffu) | (slot_of() << 9);
         if (has[1]) {  // diffuse lobe (:306-323)
-            const f3 l = normalize3(mul_tbn(tbn.t, tbn.b, tbn.n, cos_dir(u0, u1)));
+            const f3 l = l_diff;
             const f3 h = normalize3(v + l);
             const float LdH = clampf(dot3(l, h), 0.0f, 1.0f);
             const f3 F = mk3(1.0f) - fresnel_schlick(f0, f90, LdH);
             const f3 pl = F * diffuse_color * (1.0f - transmission) * atten * payload * alpha;
             emit(std::integral_constant<int, 1>{}, position + normal * 1e-5f, make_float4(l.x, l.y, l.z, __uint_as_float(nflags)), pl, LOBE_DIFFUSE);
         }
-        f3 N = tbn.n;
+        f3 N = shading_n;
         f3 offset_dir = normal;
         if (exiting) {
             N = N * -1.0f;
