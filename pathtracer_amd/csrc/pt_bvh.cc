@@ -149,6 +149,109 @@ uint32_t choose_split(std::vector<ptd::DevTri>& tris, uint32_t begin, uint32_t e
     return begin + static_cast<uint32_t>(mid - first);
 }
 
+// The split used under the four-wide nodes, where the tree need not be the reference's: surface-area heuristic over
+// bins that span the CENTROIDS of the range (not its box), right-hand sums taken over exactly the bins right of the
+// plane, and every split position tried (three sorted sweeps) once a range is small.  Always splits a range of two or
+// more triangles; returns the index of the first triangle of the right part.
+inline Box tri_box(const ptd::DevTri& t) {
+    Box b;
+    b.add_point(t.p1);
+    b.add_point(t.p2);
+    b.add_point(t.p3);
+    return b;
+}
+uint32_t choose_split_tuned(std::vector<ptd::DevTri>& tris, uint32_t begin, uint32_t end) {
+    constexpr int kBins = 32;
+    constexpr int kSweepBelow = 48;
+    const int n = static_cast<int>(end - begin);
+    ptd::DevTri* first = tris.data() + begin;
+    float clo[3] = {kMax, kMax, kMax}, chi[3] = {kLowest, kLowest, kLowest};
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float c = centroid3(first[i], a);
+            clo[a] = lo_sel(clo[a], c);
+            chi[a] = hi_sel(chi[a], c);
+        }
+    float best_cost = kInf;
+    if (n <= kSweepBelow) {
+        int order[3][kSweepBelow];
+        int best_axis = -1, best_at = 0;
+        float right_area[kSweepBelow];
+        for (int a = 0; a < 3; ++a) {
+            if (!(chi[a] > clo[a])) continue;
+            int* o = order[a];
+            for (int i = 0; i < n; ++i) o[i] = i;
+            std::stable_sort(o, o + n, [&](int x, int y) { return centroid3(first[x], a) < centroid3(first[y], a); });
+            Box acc;
+            for (int i = n - 1; i > 0; --i) {
+                acc.add_box(tri_box(first[o[i]]));
+                right_area[i] = acc.half_area();
+            }
+            Box left;
+            for (int i = 1; i < n; ++i) {  // i triangles on the left
+                left.add_box(tri_box(first[o[i - 1]]));
+                const float cost = left.half_area() * i + right_area[i] * (n - i);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_at = i;
+                }
+            }
+        }
+        if (best_axis < 0) return begin + static_cast<uint32_t>(n / 2);
+        ptd::DevTri tmp[kSweepBelow];
+        for (int i = 0; i < n; ++i) tmp[i] = first[order[best_axis][i]];
+        for (int i = 0; i < n; ++i) first[i] = tmp[i];
+        return begin + static_cast<uint32_t>(best_at);
+    }
+    struct Bin {
+        Box box;
+        int n = 0;
+    };
+    int best_axis = -1, best_bin = 0;
+    float best_scale = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        if (!(chi[a] > clo[a])) continue;
+        const float scale = static_cast<float>(kBins) / (chi[a] - clo[a]);
+        std::array<Bin, kBins> bins;
+        for (int i = 0; i < n; ++i) {
+            const int b = std::clamp(static_cast<int>((centroid3(first[i], a) - clo[a]) * scale), 0, kBins - 1);
+            ++bins[b].n;
+            bins[b].box.add_box(tri_box(first[i]));
+        }
+        float right_area[kBins];
+        int right_n[kBins];
+        Box acc;
+        int cnt = 0;
+        for (int b = kBins - 1; b > 0; --b) {
+            acc.add_box(bins[b].box);
+            cnt += bins[b].n;
+            right_area[b] = acc.empty() ? 0.0f : acc.half_area();
+            right_n[b] = cnt;
+        }
+        Box left;
+        int left_n = 0;
+        for (int b = 1; b < kBins; ++b) {  // plane between bin b - 1 and bin b
+            left.add_box(bins[b - 1].box);
+            left_n += bins[b - 1].n;
+            if (left_n == 0 || right_n[b] == 0) continue;
+            const float cost = left.half_area() * left_n + right_area[b] * right_n[b];
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_axis = a;
+                best_bin = b;
+                best_scale = scale;
+            }
+        }
+    }
+    if (best_axis < 0) return begin + static_cast<uint32_t>(n / 2);  // every centroid in one place
+    const float lo = clo[best_axis];
+    ptd::DevTri* mid = std::partition(first, first + n, [=](const ptd::DevTri& t) {
+        return std::clamp(static_cast<int>((centroid3(t, best_axis) - lo) * best_scale), 0, kBins - 1) < best_bin;
+    });
+    return begin + static_cast<uint32_t>(mid - first);
+}
+
 inline void fnv_u32(uint64_t& h, uint32_t v) {
     for (int i = 0; i < 4; ++i) {
         h ^= (v >> (8 * i)) & 0xffu;
@@ -166,8 +269,8 @@ struct Task {
 // parse (:406-447) with an explicit work list: left ranges are processed before right ranges, so nodes are numbered
 // in depth-first order.  Ranges of at most `defer_below` triangles (when non-zero) are recorded in `deferred` with their
 // box already stored in the parent, instead of being expanded.
-void build_range(std::vector<ptd::DevTri>& tris, Task first, uint32_t max_leaf, std::vector<ptd::DevNode>& nodes, uint32_t* root,
-                 uint32_t defer_below, std::vector<Task>* deferred) {
+void build_range(std::vector<ptd::DevTri>& tris, Task first, uint32_t max_leaf, bool tuned, std::vector<ptd::DevNode>& nodes,
+                 uint32_t* root, uint32_t defer_below, std::vector<Task>* deferred) {
     std::vector<Task> work{first};
     while (!work.empty()) {
         const Task tk = work.back();
@@ -180,7 +283,7 @@ void build_range(std::vector<ptd::DevTri>& tris, Task first, uint32_t max_leaf, 
             deferred->push_back(tk);
         } else {
             uint32_t mid = tk.end;
-            if (count > max_leaf) mid = choose_split(tris, tk.begin, tk.end, box, max_leaf);
+            if (count > max_leaf) mid = tuned ? choose_split_tuned(tris, tk.begin, tk.end) : choose_split(tris, tk.begin, tk.end, box, max_leaf);
             if (mid == tk.end) {
                 tris[tk.begin].leaf_count = count;
                 ref = PT_LEAF_BIT | tk.begin;
@@ -249,7 +352,7 @@ void collect_info(MeshTree& t, uint32_t n_real_tris) {  // collect_tree_info, :5
 }
 
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
-                     bool single_leaf, MeshTree& out) {
+                     bool single_leaf, bool tuned, MeshTree& out) {
     out.nodes.clear();
     out.tris.clear();
     const uint32_t n_tris = n_indices / 3;
@@ -288,7 +391,7 @@ void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint
     const char* env = std::getenv("PTGPU_BUILD_THREADS");
     const unsigned n_threads = env ? static_cast<unsigned>(std::max(1, std::atoi(env))) : hw;
     const uint32_t defer_below = (n_threads > 1 && n_tris >= (1u << 16)) ? std::max<uint32_t>(n_tris / (n_threads * 8u), max_leaf) : 0u;
-    build_range(out.tris, Task{0u, n_tris, PT_NO_NODE, false}, max_leaf, out.nodes, &out.root, defer_below, &deferred);
+    build_range(out.tris, Task{0u, n_tris, PT_NO_NODE, false}, max_leaf, tuned, out.nodes, &out.root, defer_below, &deferred);
     if (!deferred.empty()) {
         struct Subtree {
             std::vector<ptd::DevNode> nodes;
@@ -298,7 +401,8 @@ void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint
         std::atomic<size_t> next{0};
         auto worker = [&]() {
             for (size_t i; (i = next.fetch_add(1)) < deferred.size();)
-                build_range(out.tris, Task{deferred[i].begin, deferred[i].end, PT_NO_NODE, false}, max_leaf, subs[i].nodes, &subs[i].root, 0, nullptr);
+                build_range(out.tris, Task{deferred[i].begin, deferred[i].end, PT_NO_NODE, false}, max_leaf, tuned, subs[i].nodes, &subs[i].root, 0,
+                            nullptr);
         };
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < n_threads; ++t) pool.emplace_back(worker);

@@ -26,8 +26,11 @@ struct MeshTree {
 
 // Build the BVH of one mesh.  `max_leaf` = maxTrianglesPerBVHLeaf; `single_leaf` puts every triangle
 // into one leaf in mesh order (the brute-force NaiveAS of acceleration_structure.cc:299-340).
+// `tuned_splits` leaves the reference's tree for one of lower expected cost (bins over the centroid range, exact
+// right-hand sums, every split position tried in small ranges): for the four-wide nodes, which do not keep the
+// reference's visiting order anyway.  Same closest hits, up to ties in distance.
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
-                     bool single_leaf, MeshTree& out);
+                     bool single_leaf, bool tuned_splits, MeshTree& out);
 
 // Device-side alternative (pt_lbvh.hip): a linear BVH over Morton-ordered triangles, built on the GPU of the current
 // device and read back into the same structure.  Different tree, same closest hits (up to ties in distance).

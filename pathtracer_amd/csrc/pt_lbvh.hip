@@ -247,7 +247,7 @@ bool build_mesh_tree_lbvh(const ptgpu_vertex* vertices, const uint32_t* indices,
                           MeshTree& out, std::string* err) {
     const uint32_t n = n_indices / 3;
     if (n <= std::max<uint32_t>(max_leaf, 1u)) {  // nothing to split: the host builder's single leaf
-        build_mesh_tree(vertices, indices, n_indices, max_leaf, true, out);
+        build_mesh_tree(vertices, indices, n_indices, max_leaf, true, false, out);
         return true;
     }
     if (n >= (1u << 29)) {

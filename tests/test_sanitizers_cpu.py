@@ -48,4 +48,4 @@ def test_host_readers_under_sanitizers(tmp_path):
 
 def test_tree_builder_under_sanitizers():
     out = run([tool("san_bvh")])
-    assert "far leaf 1 single 0" in out and "flat leaf 8 single 0" in out and "empty leaf 64 single 1" in out
+    assert "far leaf 1 form 0" in out and "flat leaf 8 form 2" in out and "empty leaf 64 form 1" in out

@@ -1,6 +1,6 @@
 // san_bvh — runs the library's host tree builder (pathtracer_amd/csrc/pt_bvh.cc) in a build whose host code is
 // instrumented with AddressSanitizer and UndefinedBehaviorSanitizer: seeded triangle soups of several sizes and
-// shapes (compact, far from the origin, degenerate, all centroids equal), every leaf size, the single-leaf form and the
+// shapes (compact, far from the origin, degenerate, all centroids equal), every leaf size, the reference's and the tuned splits, the single-leaf form and the
 // instance table.  No GPU call is made.  Prints a checksum per case.
 #include <cstdint>
 #include <cstdio>
@@ -32,12 +32,12 @@ int main() {
             }
         }
         for (uint32_t leaf : {1u, 2u, 8u, 64u})
-            for (bool single : {false, true}) {
+            for (int form = 0; form < 3; ++form) {  // the reference's splits, one leaf, the tuned splits
                 pth::MeshTree tree;
-                pth::build_mesh_tree(verts.data(), idx.data(), static_cast<uint32_t>(idx.size()), leaf, single, tree);
+                pth::build_mesh_tree(verts.data(), idx.data(), static_cast<uint32_t>(idx.size()), leaf, form == 1, form == 2, tree);
                 pth::relocate(tree, 7u, 11u);
-                std::printf("%s leaf %u single %d: nodes %zu tris %zu depth %u checksum %016llx\n", c.name, leaf, single ? 1 : 0,
-                            tree.nodes.size(), tree.tris.size(), tree.info.max_depth, static_cast<unsigned long long>(tree.info.checksum));
+                std::printf("%s leaf %u form %d: nodes %zu tris %zu depth %u checksum %016llx\n", c.name, leaf, form, tree.nodes.size(),
+                            tree.tris.size(), tree.info.max_depth, static_cast<unsigned long long>(tree.info.checksum));
             }
         if (c.n_tris) {  // an instance table over three placements of the mesh
             ptgpu_mesh mesh{0u, static_cast<uint32_t>(verts.size()), 0u, static_cast<uint32_t>(idx.size()), 0u};
