@@ -30,6 +30,7 @@ if mode == "sorted":
     lo = o.min(0); hi = o.max(0)
     order = sys.argv[2] if len(sys.argv) > 2 else "od"
     bits = 10 if order == "fine" else (int(order[4:]) if order.startswith("bits") else 4)
+    if order.startswith("local"): bits = 4
     if order == "hit":  # cells of the point the ray came from are replaced by where it goes: origin + direction * (scene size / 4)
         o_key = o + d * float(np.linalg.norm(hi - lo)) * 0.25
     else:
@@ -43,6 +44,21 @@ if mode == "sorted":
     morton = spread(cell[:, 0]) | (spread(cell[:, 1]) << 1) | (spread(cell[:, 2]) << 2)
     octant = (d[:, 0] < 0).astype(np.int64) | ((d[:, 1] < 0).astype(np.int64) << 1) | ((d[:, 2] < 0).astype(np.int64) << 2)
     key = ((octant << 12) | morton) if order == "od" else (morton if order.startswith("bits") else ((morton << 3) | octant))
+    if order.startswith("local"):  # reorder inside windows of W consecutive rays only: by octant ("localW") or octant + fine cell ("localfullW")
+        full = order.startswith("localfull")
+        W = int(order[9:] if full else order[5:])
+        window = np.arange(n, dtype=np.int64) // W
+        if full:
+            cell10 = np.clip(((o - lo) / np.maximum(hi - lo, 1e-9) * 1024).astype(np.int64), 0, 1023)
+            def spread10(v):
+                r = np.zeros_like(v)
+                for b_ in range(10):
+                    r |= ((v >> b_) & 1) << (3 * b_)
+                return r
+            m30 = spread10(cell10[:, 0]) | (spread10(cell10[:, 1]) << 1) | (spread10(cell10[:, 2]) << 2)
+            key = (window << 33) | (octant << 30) | m30
+        else:
+            key = (window << 3) | octant
     perm = np.argsort(key, kind="stable")
     o = np.ascontiguousarray(o[perm]); d = np.ascontiguousarray(d[perm])
 for rep in range(3):
