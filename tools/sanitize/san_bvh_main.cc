@@ -1,7 +1,8 @@
 // san_bvh — runs the library's host tree builder (pathtracer_amd/csrc/pt_bvh.cc) in a build whose host code is
 // instrumented with AddressSanitizer and UndefinedBehaviorSanitizer: seeded triangle soups of several sizes and
 // shapes (compact, far from the origin, degenerate, all centroids equal), every leaf size, the reference's and the tuned splits, the single-leaf form and the
-// instance table.  No GPU call is made.  Prints a checksum per case.
+// instance table, and checks every tree (each triangle in exactly one leaf, leaf sizes, boxes nested).  No GPU call is
+// made.  Prints a checksum per case.
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -9,6 +10,55 @@
 #include <vector>
 
 #include "pt_bvh.h"
+
+// Every triangle in exactly one leaf, no leaf above the limit (unless the whole mesh is one leaf), every child box inside
+// nothing smaller than the triangles below it.  Returns an error text or nullptr.
+static const char* check_tree(const pth::MeshTree& t, uint32_t n_tris, uint32_t max_leaf, bool single) {
+    if (n_tris == 0) return nullptr;
+    std::vector<int> seen(n_tris, 0);
+    struct Item { uint32_t ref; float lo[3], hi[3]; bool boxed; };
+    std::vector<Item> todo;
+    Item root{};
+    root.ref = t.root;
+    root.boxed = false;
+    todo.push_back(root);
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.ref & PT_LEAF_BIT) {
+            const uint32_t first = it.ref & ~PT_LEAF_BIT;
+            if (first >= t.tris.size()) return "leaf reference out of range";
+            const uint32_t count = t.tris[first].leaf_count;
+            if (count == 0 || first + count > t.tris.size()) return "bad leaf count";
+            if (!single && n_tris > max_leaf && count > max_leaf) return "leaf above the limit";
+            for (uint32_t k = 0; k < count; ++k) {
+                const ptd::DevTri& tr = t.tris[first + k];
+                if (tr.index % 3 || tr.index / 3 >= n_tris) return "bad triangle index";
+                ++seen[tr.index / 3];
+                if (it.boxed)
+                    for (const float* p : {tr.p1, tr.p2, tr.p3})
+                        for (int a = 0; a < 3; ++a)
+                            if (p[a] < it.lo[a] || p[a] > it.hi[a]) return "triangle outside its parent's box";
+            }
+            continue;
+        }
+        if (it.ref >= t.nodes.size()) return "node reference out of range";
+        const ptd::DevNode& nd = t.nodes[it.ref];
+        Item l{}, r{};
+        l.ref = nd.left; r.ref = nd.right;
+        l.boxed = r.boxed = true;
+        std::memcpy(l.lo, nd.l_lo, 12); std::memcpy(l.hi, nd.l_hi, 12);
+        std::memcpy(r.lo, nd.r_lo, 12); std::memcpy(r.hi, nd.r_hi, 12);
+        if (it.boxed)
+            for (int a = 0; a < 3; ++a)
+                if (l.lo[a] < it.lo[a] || r.lo[a] < it.lo[a] || l.hi[a] > it.hi[a] || r.hi[a] > it.hi[a]) return "child box outside its parent's";
+        todo.push_back(r);
+        todo.push_back(l);
+    }
+    for (int v : seen)
+        if (v != 1) return "a triangle is missing or in two leaves";
+    return nullptr;
+}
 
 int main() {
     std::mt19937 rng(12345);
@@ -35,6 +85,10 @@ int main() {
             for (int form = 0; form < 3; ++form) {  // the reference's splits, one leaf, the tuned splits
                 pth::MeshTree tree;
                 pth::build_mesh_tree(verts.data(), idx.data(), static_cast<uint32_t>(idx.size()), leaf, form == 1, form == 2, tree);
+                if (const char* bad = check_tree(tree, c.n_tris, leaf, form == 1)) {
+                    std::printf("%s leaf %u form %d: %s\n", c.name, leaf, form, bad);
+                    return 1;
+                }
                 pth::relocate(tree, 7u, 11u);
                 std::printf("%s leaf %u form %d: nodes %zu tris %zu depth %u checksum %016llx\n", c.name, leaf, form, tree.nodes.size(),
                             tree.tris.size(), tree.info.max_depth, static_cast<unsigned long long>(tree.info.checksum));
