@@ -421,17 +421,18 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
 #pragma unroll
     for (int i = 0; i < 7; ++i) finite = finite && (fabsf(pr.ip[i]) < kInfF);
     const bool wave_finite = __ballot(!finite) == 0ull;  // (lanes past the end of the queue have left already)
-    uint32_t wave_filled = 0;  // wave-uniform: no lane holds more candidates than this, so later list entries are empty
+    uint32_t wave_filled = 0;  // wave-uniform: the longest list of any lane, so the entry at wave_filled is empty in every lane
     for (uint32_t k = 0; k < n_inst; ++k) {
         const float dist = wave_finite ? dop_forward_distance_finite(sc.instances[k].dop, pr) : dop_forward_distance(sc.instances[k].dop, pr);
         if (__ballot(dist < kInfF) == 0ull) continue;  // no ray of this wavefront touches the instance: skip the insertion
+        bool grew = false;
         if (dist < kInfF) {
             // sorted insertion; strict '<' keeps table order among equal distances
             float ck = any_hit ? -static_cast<float>(k) : dist;
             uint32_t cs = k;
 #pragma unroll
             for (int j = 0; j < kCandMax; ++j) {
-                if (static_cast<uint32_t>(j) > wave_filled) break;  // (uniform) the entry at wave_filled is empty in every lane
+                if (static_cast<uint32_t>(j) > wave_filled) break;  // (uniform) nothing is stored beyond the longest list
                 const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
                 const float tk = key[j];
                 const uint32_t ts = slot[j];
@@ -439,9 +440,12 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
                 slot[j] = sw ? cs : ts;
                 ck = sw ? tk : ck;
                 cs = sw ? ts : cs;
+                // only a lane whose list was the longest fills the entry at wave_filled (lanes that sit this instance out
+                // hold fewer entries than that already)
+                if (static_cast<uint32_t>(j) == wave_filled) grew = __ballot(slot[j] != PT_NO_NODE) != 0ull;
             }
         }
-        ++wave_filled;
+        if (__ballot(grew) != 0ull) ++wave_filled;
     }
     // An entry's slot word carries kCandLast when the stored list ends with it, so a list costs no terminator entry and
     // the traversal kernel knows without a read that nothing follows; an empty list is one entry with the slot PT_NO_NODE.
