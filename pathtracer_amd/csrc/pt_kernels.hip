@@ -384,23 +384,28 @@ __device__ __forceinline__ RayClaim make_claim() {
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     return RayClaim{xcc & 7u, 0u, 0u, 0u, false};
 }
-__device__ __forceinline__ void claim_block(RayClaim& c, uint32_t* __restrict__ cursors, uint32_t n, uint32_t lane) {
+// (The claim is taken and returned by value and its fields are written in one place each: a structure updated through a
+// reference from several branches ends up in scratch memory, read back on every service pass.)
+__device__ __forceinline__ RayClaim claim_block(RayClaim c, uint32_t* __restrict__ cursors, uint32_t n, uint32_t lane) {
     const uint32_t seg_len = (((n + 7u) / 8u) + PT_RAY_BLOCK - 1u) / PT_RAY_BLOCK * PT_RAY_BLOCK;
-    while (!c.exhausted) {
+    uint32_t seg = c.seg, tried = c.tried, next = 0, end = 0;
+    bool exhausted = c.exhausted, found = false;
+    while (!exhausted && !found) {
         uint32_t off = 0;
-        if (lane == 0) off = atomicAdd(cursors + c.seg * kCursorStride, static_cast<uint32_t>(PT_RAY_BLOCK));
+        if (lane == 0) off = atomicAdd(cursors + seg * kCursorStride, static_cast<uint32_t>(PT_RAY_BLOCK));
         off = __builtin_amdgcn_readfirstlane(off);
-        const uint64_t seg_first = static_cast<uint64_t>(c.seg) * seg_len;
+        const uint64_t seg_first = static_cast<uint64_t>(seg) * seg_len;
         const uint64_t seg_end = (seg_first + seg_len < n) ? seg_first + seg_len : n;
-        if (off < seg_len && seg_first + off < seg_end) {
-            c.next = static_cast<uint32_t>(seg_first + off);
-            c.end = static_cast<uint32_t>((seg_first + off + PT_RAY_BLOCK < seg_end) ? seg_first + off + PT_RAY_BLOCK : seg_end);
-            return;
+        found = off < seg_len && seg_first + off < seg_end;
+        if (found) {
+            next = static_cast<uint32_t>(seg_first + off);
+            end = static_cast<uint32_t>((seg_first + off + PT_RAY_BLOCK < seg_end) ? seg_first + off + PT_RAY_BLOCK : seg_end);
+        } else {
+            seg = (seg + 1u) & 7u;
+            exhausted = (++tried == 8u);
         }
-        c.seg = (c.seg + 1u) & 7u;
-        if (++c.tried == 8u) c.exhausted = true;
     }
-    c.next = c.end = 0;
+    return RayClaim{seg, tried, next, end, exhausted};
 }
 
 template <bool COUNT>
@@ -810,7 +815,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             if (!claim.exhausted) {
                 const unsigned long long m_free = __ballot(cur == PT_IDLE);
                 const uint32_t n_free = __popcll(m_free);
-                if (n_free && claim.next >= claim.end) claim_block(claim, next_ray, n, lane);
+                if (n_free && claim.next >= claim.end) claim = claim_block(claim, next_ray, n, lane);
                 const uint32_t avail = claim.end - claim.next;
                 const uint32_t rank = __popcll(m_free & lt_mask);
                 if (cur == PT_IDLE && rank < avail) {
