@@ -293,6 +293,8 @@ def main() -> None:
             tlas_bytes_per_ray = I * 64 + 32 + (E + 1) * 8
             traverse_s = traverse_ms / 1e3
             kernel_name = "traverse_kernel<false, false>" if args.binary_nodes else "traverse_kernel<false, true>"
+            if not args.binary_nodes and getattr(st, "traverse_workgroups_per_cu", 6) == 7:
+                kernel_name = "traverse_kernel7<false>"  # the form for scenes that the caches hold (seven workgroups per CU)
             launches = max(extend_launches, 1)
             avg_launch_s = traverse_s / launches
             rays_per_launch = rays / launches

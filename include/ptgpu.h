@@ -194,6 +194,9 @@ typedef struct ptgpu_stats {
     uint64_t wave_triangle_iterations; /* idem: triangle loop iterations summed over wavefronts */
     double traverse_ms; /* part of extend_ms spent in the traversal kernel (0 with PTGPU_EXTEND=simple) */
     uint64_t nodes_from_lds; /* ptgpu_render_counted: node visits served by the traversal kernel's LDS copy of the top nodes */
+    uint32_t traverse_workgroups_per_cu; /* form of the traversal kernel the loaded scene runs with: 6, or 7 (four-wide nodes
+                                            over a scene the caches hold); 0 with PTGPU_EXTEND=simple */
+    uint32_t reserved0;
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

@@ -109,7 +109,7 @@ class Stats(C.Structure):
         ("generate_ms", C.c_double), ("total_ms", C.c_double), ("nodes_visited", C.c_uint64),
         ("triangles_tested", C.c_uint64), ("instances_tested", C.c_uint64), ("instances_entered", C.c_uint64),
         ("wave_inner_iterations", C.c_uint64), ("wave_triangle_iterations", C.c_uint64),
-        ("traverse_ms", C.c_double), ("nodes_from_lds", C.c_uint64),
+        ("traverse_ms", C.c_double), ("nodes_from_lds", C.c_uint64), ("traverse_workgroups_per_cu", C.c_uint32), ("reserved0", C.c_uint32),
     ]
 
 

@@ -125,6 +125,7 @@ struct SceneDev {
     uint32_t n_tlas;              // its node count
     const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
     uint32_t n_top_nodes4;        // likewise for nodes4
+    uint32_t seven_waves;         // the four-wide traversal kernel runs in its seven-workgroups-per-CU form (shorter LDS stack)
     int32_t env_w, env_h;
     float env_rot;
 };

@@ -16,6 +16,10 @@ constexpr int kStackLds = PT_STACK_LDS;  // per-lane traversal stack entries kep
 constexpr int kTopNodes = 192;       // BVH nodes every traversal workgroup keeps in LDS (12 KB)
 constexpr uint32_t kXformLds = 16;   // instance transforms kept in LDS by the same kernel (2 KB)
 constexpr int kTopNodes4 = 192;      // likewise for the four-wide form (also 64 B a node)
+// the same three for the four-wide kernel that runs seven workgroups per CU (SceneDev::seven_waves)
+constexpr int kStackLds7 = 10;
+constexpr int kTopNodes7 = 176;
+constexpr uint32_t kXformLds7 = 8;
 constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
 constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
 
@@ -84,7 +88,7 @@ void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamp
 void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, uint32_t* spill,
                    uint32_t spill_depth, uint32_t spill_stride, TraceCounters* counters);
 // Workgroups that are resident at once for the persistent extend kernel (occupancy x compute units).
-uint32_t extend_persistent_grid(int device);
+uint32_t extend_persistent_grid(int device, bool seven_waves);
 // Persistent form: a fixed grid of n_blocks workgroups pulls rays from 8 cursors, one per XCD segment of the queue,
 // 128 bytes apart at next_ray (1 KiB, zeroed here).
 // `overflow` (1 + n words) lists the rays handed to the continuation pass (more than kCandMax candidate instances).

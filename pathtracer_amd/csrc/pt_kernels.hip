@@ -587,35 +587,42 @@ __device__ __forceinline__ float box_entry_fast(float lox, float loy, float loz,
 }
 
 enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u, F_LAST = 16u };  // F_LAST: the candidate list has no further entry
-template <bool COUNT, bool WIDE>
-__global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
-                                                 const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
-                                                 float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
-                                                 uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
-                                                 uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
-                                                 TraceCounters* counters) {
-    __shared__ uint32_t s_stack[kStackLds][kBlock];
+// SEVEN: the LDS budget of seven workgroups per CU instead of six (a shorter LDS stack, fewer cached nodes and transforms),
+// for the kernel that is compiled for seven wavefronts per SIMD.
+template <bool COUNT, bool WIDE, bool SEVEN>
+__device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* __restrict__ ray_o,
+                                              const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                              float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                              uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
+                                              uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
+                                              TraceCounters* counters) {
+    constexpr int kStack = SEVEN ? kStackLds7 : kStackLds;
+    constexpr int kTop = SEVEN ? kTopNodes7 : kTopNodes;
+    constexpr uint32_t kXf = SEVEN ? kXformLds7 : kXformLds;
+    __shared__ uint32_t s_stack[kStack][kBlock];
     // The most visited nodes (the first of the node array), 64 bytes each, node after node.  Layouts that spread the
     // lanes' reads over more banks (quarter-major, 80-byte stride) measured 20-40 % slower for the whole kernel.
-    __shared__ float4 s_top[kTopNodes * 4];
+    __shared__ float4 s_top[kTop * 4];
     // the transforms of the first instances (128 B each): read once per instance a ray enters, and again per accepted hit
-    __shared__ float4 s_xf[kXformLds * (sizeof(DevXform) / 16)];
+    __shared__ float4 s_xf[kXf * (sizeof(DevXform) / 16)];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     const uint32_t gthread = blockIdx.x * kBlock + tid;  // owner of one spill column
     TraceCount cnt{};
     static_assert(kTopNodes4 <= kTopNodes && sizeof(Node4) == sizeof(NodeQ), "the four-wide node cache fits the same LDS array");
-    const uint32_t n_top = WIDE ? sc.n_top_nodes4 : sc.n_top_nodes;
+    static_assert(!SEVEN || WIDE, "the seven-wave budget is for the four-wide kernel");
+    const uint32_t n_top_scene = WIDE ? sc.n_top_nodes4 : sc.n_top_nodes;
+    const uint32_t n_top = n_top_scene < static_cast<uint32_t>(kTop) ? n_top_scene : static_cast<uint32_t>(kTop);
     {
         const float4* src = WIDE ? reinterpret_cast<const float4*>(sc.nodes4) : reinterpret_cast<const float4*>(sc.nodes);
         for (uint32_t i = tid; i < n_top * 4u; i += kBlock) s_top[i] = src[i];
-        const uint32_t n_xf = (sc.n_instances < kXformLds ? sc.n_instances : kXformLds) * (sizeof(DevXform) / 16);
+        const uint32_t n_xf = (sc.n_instances < kXf ? sc.n_instances : kXf) * (sizeof(DevXform) / 16);
         if (tid < n_xf) s_xf[tid] = reinterpret_cast<const float4*>(sc.xforms)[tid];
     }
     __syncthreads();
     auto xform_record = [&](uint32_t k) -> const DevXform& {
-        return (k < kXformLds) ? reinterpret_cast<const DevXform*>(s_xf)[k] : sc.xforms[k];
+        return (k < kXf) ? reinterpret_cast<const DevXform*>(s_xf)[k] : sc.xforms[k];
     };
 
     // ---- per-lane state ----
@@ -639,11 +646,11 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
     // The top of the stack is read when a step starts, together with the node or triangle, so that a pop costs
     // no second round trip; only the rare entry beyond the LDS part is fetched when it is needed.
     auto peek = [&]() -> uint32_t {
-        const int at = (sp > kStackLds) ? kStackLds - 1 : sp - 1;
+        const int at = (sp > kStack) ? kStack - 1 : sp - 1;
         return (sp > 0) ? s_stack[at][tid] : PT_NO_NODE;
     };
     auto pop_to = [&](uint32_t top) {
-        if (sp > kStackLds) top = spill[static_cast<size_t>(sp - 1 - kStackLds) * spill_stride + gthread];
+        if (sp > kStack) top = spill[static_cast<size_t>(sp - 1 - kStack) * spill_stride + gthread];
         cur = top;
         sp = (sp > 0) ? sp - 1 : 0;
     };
@@ -716,9 +723,9 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             order(d0, r0, d2, r2);
 #endif
             auto push = [&](uint32_t ref) {
-                if (sp < kStackLds) s_stack[sp][tid] = ref;
-                else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
-                    spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = ref;
+                if (sp < kStack) s_stack[sp][tid] = ref;
+                else if (static_cast<uint32_t>(sp - kStack) < spill_depth)
+                    spill[static_cast<size_t>(sp - kStack) * spill_stride + gthread] = ref;
                 ++sp;
             };
             if (d0 < kInfF) {  // nearest first; the others wait on the stack, the nearer the higher
@@ -896,9 +903,9 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
                     const uint32_t near_ref = l_first ? left : right, far_ref = l_first ? right : left;
                     const float d_near = l_first ? dl : dr, d_far = l_first ? dr : dl;
                     if (h_t > d_far) {
-                        if (sp < kStackLds) s_stack[sp][tid] = far_ref;
-                        else if (static_cast<uint32_t>(sp - kStackLds) < spill_depth)
-                            spill[static_cast<size_t>(sp - kStackLds) * spill_stride + gthread] = far_ref;
+                        if (sp < kStack) s_stack[sp][tid] = far_ref;
+                        else if (static_cast<uint32_t>(sp - kStack) < spill_depth)
+                            spill[static_cast<size_t>(sp - kStack) * spill_stride + gthread] = far_ref;
                         ++sp;
                         cur = near_ref;
                     } else if (h_t > d_near) {
@@ -995,6 +1002,27 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
             for (int ph = 0; ph < 4; ++ph)
                 for (int k = 0; k < 6; ++k) atomicAdd(&counters->census[ph][k], static_cast<unsigned long long>(cnt.census[ph][k]));
     }
+}
+template <bool COUNT, bool WIDE>
+__global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
+                                                 const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                                 float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                                 uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
+                                                 uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
+                                                 TraceCounters* counters) {
+    traverse_body<COUNT, WIDE, false>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+}
+// The four-wide kernel at seven wavefronts per SIMD (72 registers, 22 KB of LDS per workgroup).  Scenes that the caches
+// hold are limited by the latency of a step, and a seventh wavefront hides more of it (2.5-4 % faster); scenes that are
+// limited by the gather path (the 10 M-triangle mesh) and the binary layout run 4-7 % slower that way and keep six.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock, 7) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
+                                                              const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
+                                                              float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
+                                                              uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
+                                                              uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
+                                                              TraceCounters* counters) {
+    traverse_body<COUNT, true, true>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 
 // Continuation for rays with more than kCandMax candidate instances (a rarity: that many bounding volumes pierced
@@ -1814,9 +1842,11 @@ void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n
         PT_LAUNCH(extend_kernel<false>, dim3(blocks_for(n)), dim3(kBlock), 0, st, sc, rays.o, rays.d, n, hits.h0,
                            hits.h1, spill, spill_depth, spill_stride, counters);
 }
-uint32_t extend_persistent_grid(int device) {
+uint32_t extend_persistent_grid(int device, bool seven_waves) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false, false>, kBlock, 0) != hipSuccess || per_cu < 1)
+    const hipError_t e = seven_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel7<false>, kBlock, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false, false>, kBlock, 0);
+    if (e != hipSuccess || per_cu < 1)
         per_cu = 2;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) cus = 256;
     return static_cast<uint32_t>(per_cu) * static_cast<uint32_t>(cus);
@@ -1837,6 +1867,7 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         else PT_LAUNCH(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
+        // (the counting form always runs as the six-workgroup kernel: its counters do not fit the seven-wave register budget)
         if (sc.nodes4)
             PT_LAUNCH((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
@@ -1849,7 +1880,10 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         else PT_LAUNCH(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        if (sc.nodes4)
+        if (sc.nodes4 && sc.seven_waves)
+            PT_LAUNCH(traverse_kernel7<false>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (sc.nodes4)
             PT_LAUNCH((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         else

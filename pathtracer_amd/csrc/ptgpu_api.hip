@@ -289,6 +289,12 @@ uint32_t fanout_of(const ptgpu_settings& s) {
 }
 
 // K = camera samples per batch (sizes the ray pools), L = largest launch (sizes hit records, candidate lists, overflow list)
+// Stack entries beyond the LDS part of the traversal kernel in use (the seven-wave kernel keeps fewer in LDS).
+uint32_t spill_depth_of(const ptgpu_ctx* c) {
+    const uint32_t in_lds = c->scene.seven_waves ? ptd::kStackLds7 : ptd::kStackLds;
+    return c->max_depth > in_lds ? c->max_depth - in_lds : 0;
+}
+
 int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t K, uint64_t L) {
     (void)ptd::take_launch_error(nullptr);  // a launch failure left over from a call that ended early is not this call's
     K = std::max<uint64_t>(K, c->batch_cap);
@@ -319,9 +325,9 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     }
     PT_HIP(c, c->hit0.ensure(L * 16));
     PT_HIP(c, c->hit1.ensure(L * 4));
-    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    const uint32_t spill_depth = spill_depth_of(c);
     if (c->persistent && !c->persist_blocks) {
-        c->persist_blocks = ptd::extend_persistent_grid(c->device);
+        c->persist_blocks = ptd::extend_persistent_grid(c->device, c->scene.seven_waves != 0);
         if (const char* b = std::getenv("PTGPU_PERSIST_BLOCKS")) c->persist_blocks = static_cast<uint32_t>(std::max(1, std::atoi(b)));
         if (std::getenv("PTGPU_VERBOSE")) std::fprintf(stderr, "[ptgpu] persistent extend grid: %u workgroups\n", c->persist_blocks);
     }
@@ -339,7 +345,7 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
 
 void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t n, const ptd::HitQueue& hits,
                 ptd::TraceCounters* tc, hipEvent_t between = nullptr) {
-    const uint32_t spill_depth = c->max_depth > ptd::kStackLds ? c->max_depth - ptd::kStackLds : 0;
+    const uint32_t spill_depth = spill_depth_of(c);
     if (c->persistent)
         ptd::launch_extend_persistent(st, c->scene, rq, n, hits, ptd::CandQueue{c->cand.as<uint2>(), c->launch_cap},
                                       c->spill.as<uint32_t>(), spill_depth, c->persist_blocks, c->ray_cursor.as<uint32_t>(),
@@ -542,6 +548,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     PT_SYNC(c, st);
     PT_HIP(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     out.total_ms = ms;
+    out.traverse_workgroups_per_cu = c->persistent ? (c->scene.nodes4 && c->scene.seven_waves ? 7u : 6u) : 0u;
     if (counted) {
         ptd::TraceCounters tc;
         PT_HIP(c, hipMemcpy(&tc, d_tc, sizeof(tc), hipMemcpyDeviceToHost));
@@ -872,6 +879,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     // ---- optional four-wide nodes (PTGPU_FLAG_WIDE_NODES): inner children pulled up into their parent, largest box first ----
     std::vector<ptd::Node4> wide;
     uint32_t n_top4 = 0;
+    bool seven_waves = false;
     if (want_wide && !all_nodes.empty()) {
         struct Child {
             uint32_t ref;
@@ -1072,6 +1080,15 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
             }
         }
         for (ptd::DevXform& xf : table.xforms) xf.root4 = mesh_root4[xf.mesh_index];
+        // Which form of the four-wide kernel: seven workgroups per CU when nodes and triangles fit the Infinity Cache with room
+        // to spare (the kernel is then limited by the latency of a step), six otherwise (limited by the gather path: more
+        // wavefronts only add to it).  PTGPU_TRAVERSE_WAVES=6 / 7 overrides.
+        {
+            const uint64_t geometry_bytes = static_cast<uint64_t>(wide.size()) * sizeof(ptd::Node4) + (all_tris.size() + 2) * sizeof(ptd::TriQ);
+            seven_waves = geometry_bytes <= (128ull << 20);
+            if (const char* e = std::getenv("PTGPU_TRAVERSE_WAVES")) seven_waves = std::atoi(e) == 7;
+        }
+        const size_t top_capacity4 = seven_waves ? ptd::kTopNodes7 : ptd::kTopNodes4;
         // the most visited wide nodes first (same estimate as for the binary nodes), kept in LDS by the kernel
         {
             struct Entry {
@@ -1084,7 +1101,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
                 if (mesh_root4[m] != PT_NO_NODE && !(mesh_root4[m] & PT_LEAF_BIT) && mesh_weight[m] > 0.0f)
                     queue.push({std::numeric_limits<float>::max(), mesh_root4[m], m});
             std::vector<uint32_t> order;
-            while (!queue.empty() && order.size() < static_cast<size_t>(ptd::kTopNodes4)) {
+            while (!queue.empty() && order.size() < top_capacity4) {
                 const Entry e = queue.top();
                 queue.pop();
                 order.push_back(e.node);
@@ -1118,7 +1135,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
         // a visit pushes up to three children: the stack can hold 3 entries per level
         c->max_depth = std::max(c->max_depth, 3u * max_depth4 + 1u);
         if (std::getenv("PTGPU_VERBOSE"))
-            std::fprintf(stderr, "[ptgpu] four-wide nodes: %zu (from %zu binary), depth %u\n", wide.size(), all_nodes.size(), max_depth4);
+            std::fprintf(stderr, "[ptgpu] four-wide nodes: %zu (from %zu binary), depth %u, kernel form: %d workgroups per CU\n", wide.size(),
+                         all_nodes.size(), max_depth4, seven_waves ? 7 : 6);
     }
 
     // ---- shading data ----
@@ -1266,6 +1284,8 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.tlas = tlas.empty() ? nullptr : c->tlas.as<ptd::TlasNode>();
     sc.n_tlas = static_cast<uint32_t>(tlas.size());
     sc.n_top_nodes4 = n_top4;
+    sc.seven_waves = seven_waves ? 1u : 0u;
+    c->persist_blocks = 0;  // the resident grid depends on the kernel form: sized again at the next render
     sc.env_w = env_w;
     sc.env_h = env_h;
     sc.env_rot = s.envmap_rotation;
@@ -1453,7 +1473,7 @@ int ptgpu_intersect_rays_static(ptgpu_ctx* c, uint32_t n, const float* d_origins
     if (!c->static_scratch) return c->fail(PTGPU_E_STATE, "intersect_rays_static: device %d has no built-in work array", c->device);
     if (n > kStaticMaxRays)
         return c->fail(PTGPU_E_INVALID, "intersect_rays_static: %u rays in one call, the built-in work array holds %u", n, kStaticMaxRays);
-    const uint32_t spill_depth = c->max_depth > static_cast<uint32_t>(ptd::kStackLds) ? c->max_depth - ptd::kStackLds : 0;
+    const uint32_t spill_depth = spill_depth_of(c);
     if (spill_depth > kStaticSpillDepth)
         return c->fail(PTGPU_E_NOMEM, "intersect_rays_static: the scene's trees need %u spilled stack entries per thread, the built-in work array holds %u",
                        spill_depth, kStaticSpillDepth);

@@ -296,6 +296,34 @@ def test_wide_nodes_give_the_same_results(tiny, materials, scene, as_type):
     assert exact.mean() >= 0.9999
 
 
+def test_both_forms_of_the_wide_kernel_agree(materials):
+    """The four-wide traversal kernel exists in two forms — six or seven workgroups per CU, with LDS stacks of 12 or 10
+    entries and 192 or 176 cached nodes; which one runs is chosen by the size of the scene (PTGPU_TRAVERSE_WAVES overrides).
+    Same tree, same steps per ray: closest-hit records, any-hit flags and ray counts are equal to the bit, on a deep mesh
+    (stack entries beyond the LDS part) and on the scene with every material feature."""
+    rng = np.random.default_rng(5)
+    n = 40000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    any_flags = np.ones(n, np.uint8)
+    w, h = 200, 120
+    for model, env in ((scenes.stress_mesh(400_000), None), materials):
+        results = []
+        for waves in ("6", "7"):
+            os.environ["PTGPU_TRAVERSE_WAVES"] = waves
+            try:
+                g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=True), w, h)
+            finally:
+                os.environ.pop("PTGPU_TRAVERSE_WAVES", None)
+            img, st = H.gpu_render(g, w, h)
+            results.append((g.intersect_rays(org, d), g.intersect_rays(org, d, any_flags)["hit"], int(st.rays), img))
+        (c6, a6, r6, i6), (c7, a7, r7, i7) = results
+        exact, _ = H.hits_equal(c6, c7)
+        assert exact.all() and (a6 == a7).all() and r6 == r7
+        assert np.abs(i6 - i7).max() <= 2e-5 * max(1.0, float(np.abs(i6).max()))  # (the framebuffer's summation order is not fixed)
+
+
 @pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
 def test_random_soups_both_node_layouts(seed, offset, flat):
     """Unstructured triangle soups under random affine transforms, also far from the object-space origin (box planes and
