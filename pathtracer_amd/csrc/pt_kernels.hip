@@ -772,39 +772,52 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 // A ray that has consumed the last entry of its candidate list needs neither its direction nor another
                 // list entry, and its origin only to turn a hit's distance into world space.
                 const bool more = fresh || !(flags & F_LAST);
-                float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = ro;
-                if (more) {
-                    ro = ray_o[rid];
-                    rd = ray_d[rid];
-                } else if (h_hit) {
-                    ro = ray_o[rid];
-                }
+                // The next list entry is asked for together with the ray, both words at once, although whether it is needed
+                // (an any-hit ray that just found its hit needs none) and whether its distance is looked at is only known
+                // after the ray has arrived: one round trip for the whole pick instead of up to three in a row, while every
+                // lane of the wavefront waits.  The three loads are unconditional so that nothing separates them; a lane
+                // that needs none of a record reads record 0 instead (one cache line for all such lanes, no bytes from memory).
+                const bool entry_stored = more && cursor < kCandMax;
+                const float4 ro = ray_o[(more || h_hit) ? rid : 0u];
+                const float4 rd = ray_d[more ? rid : 0u];
+                const uint2 e = cand.e[entry_stored ? static_cast<size_t>(cursor) * cand.stride + rid : 0u];
+                uint32_t e_x = e.x, e_y = e.y, rd_w = __float_as_uint(rd.w);
+                // (an empty statement that "uses" the entry and the ray's flag word here: without it the compiler moves each
+                // word's load down to the branch that looks at it, behind the wait for the ray, and the round trips are in
+                // a row again)
+                asm volatile("" : "+v"(e_x), "+v"(e_y), "+v"(rd_w));
+                const float e_key = __uint_as_float(e_x);
+                const uint32_t e_slot = e_y;
                 ow = ld3(ro);
                 dw = ld3(rd);
                 if (fresh) {
-                    if ((__float_as_uint(rd.w) >> 8) & 1u) flags |= F_ANY;
+                    if ((rd_w >> 8) & 1u) flags |= F_ANY;
                 } else if (h_hit) {
                     // back to a world-space distance and acceptance (acceleration_structure.cc:704-706, 616-623)
                     const DevXform& xf = xform_record(slot);
+                    uint32_t object_index = xf.object_index;
                     const f3 p = o + d * h_t;
                     const f3 p_ws = xform(xf.model, p, 1.0f);
+                    // (read with the matrix and kept there: read after the comparison below, the store of the flag word would
+                    // wait for this load and with it for the store of the distance record before it)
+                    asm volatile("" : "+v"(object_index));
                     const float t_ws = length3(p_ws - ow);
                     if ((t_ws > 0.0f) && (t_ws < b_t)) {
                         b_t = t_ws;
                         flags |= F_BHIT;
                         hit0[rid] = make_float4(t_ws, h_A, h_B, __uint_as_float(h_tri));
-                        hit1[rid] = xf.object_index | (h_back ? 0x40000000u : 0u) | 0x80000000u;
+                        hit1[rid] = object_index | (h_back ? 0x40000000u : 0u) | 0x80000000u;
                     }
                 }
                 const bool any_hit = (flags & F_ANY) != 0;
                 bool deferred = false;
                 if (more && !(any_hit && (flags & F_BHIT))) {
-                    if (cursor < kCandMax) {
-                        const uint2 e = cand.e[static_cast<size_t>(cursor) * cand.stride + rid];
+                    if (entry_stored) {
                         ++cursor;
-                        if (e.y != PT_NO_NODE) {
-                            if (e.y & kCandLast) flags |= F_LAST;
-                            if (any_hit || (__uint_as_float(e.x) < b_t)) enter_slot = e.y & ~kCandLast;
+                        const bool nearer = e_key < b_t;
+                        if (e_slot != PT_NO_NODE) {
+                            if (e_slot & kCandLast) flags |= F_LAST;
+                            if (any_hit || nearer) enter_slot = e_slot & ~kCandLast;
                         }
                     } else {
                         deferred = true;  // all stored candidates are used up: the continuation pass takes the ray
