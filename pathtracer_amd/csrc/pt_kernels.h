@@ -17,9 +17,12 @@ constexpr int kTopNodes = 192;       // BVH nodes every traversal workgroup keep
 constexpr uint32_t kXformLds = 16;   // instance transforms kept in LDS by the same kernel (2 KB)
 constexpr int kTopNodes4 = 192;      // likewise for the four-wide form (also 64 B a node)
 // the same three for the four-wide kernel that runs seven workgroups per CU (SceneDev::seven_waves)
+#ifndef PT_XFORM_LDS7
+#define PT_XFORM_LDS7 12
+#endif
 constexpr int kStackLds7 = 10;
 constexpr int kTopNodes7 = 176;
-constexpr uint32_t kXformLds7 = 8;
+constexpr uint32_t kXformLds7 = PT_XFORM_LDS7;
 constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
 constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
 
