@@ -8,7 +8,7 @@ acc = collections.defaultdict(float)
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     run = f.split("/")[-3] if f.split("/")[-2].startswith("vm") or True else ""
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(\w+_kernel(?:<[\w, ]+>)?)", r["Kernel_Name"])
+        m = re.search(r"(\w+_kernel\d*(?:<[\w, ]+>)?)", r["Kernel_Name"])
         if not m:
             continue
         acc[(m.group(1), r["Counter_Name"])] += float(r["Counter_Value"])
