@@ -40,9 +40,11 @@ struct HitQueue {
     uint32_t* h1;
 };
 
-// Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot).  The slot word
+// Candidate instances per ray in visiting order: e[k * stride + ray] = (entry distance bits, instance slot) for k >= 1.  The
+// first candidate is one word, first()[ray] = its slot: its distance is never looked at (a ray that has no hit yet enters its
+// first candidate whatever the distance), and the words live in the first half of what would be plane 0 of `e`.  The slot word
 // of the last stored entry carries kCandLast unless the list is full (kCandMax entries: it may go on, a rescan continues it);
-// a ray without candidates has the one entry (-, PT_NO_NODE).
+// a ray without candidates has first()[ray] = PT_NO_NODE.
 #ifndef PT_CAND_MAX
 #define PT_CAND_MAX 8
 #endif
@@ -56,7 +58,9 @@ constexpr uint32_t kTlasLds = 512;       // nodes of that tree kept in LDS by th
 struct CandQueue {
     uint2* e;
     uint32_t stride;
+    __host__ __device__ uint32_t* first() const { return reinterpret_cast<uint32_t*>(e); }
 };
+static_assert(kCandMax >= 2, "the continuation pass reads the last entry with its distance");
 
 struct CameraDev {
     float ndc2world[16];  // column-major

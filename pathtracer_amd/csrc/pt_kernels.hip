@@ -458,8 +458,9 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
     for (int j = 0; j < kCandMax; ++j)
         if (j == 0 || slot[j] != PT_NO_NODE) {
             const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
-            cand.e[static_cast<size_t>(j) * cand.stride + gid] =
-                make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j] | (last ? kCandLast : 0u));
+            const uint32_t word = slot[j] | (last ? kCandLast : 0u);
+            if (j == 0) cand.first()[gid] = word;  // (the first candidate's distance is never looked at)
+            else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
 }
@@ -551,8 +552,9 @@ __global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const fl
     for (int j = 0; j < kCandMax; ++j)
         if (j == 0 || slot[j] != PT_NO_NODE) {
             const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
-            cand.e[static_cast<size_t>(j) * cand.stride + gid] =
-                make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), slot[j] | (last ? kCandLast : 0u));
+            const uint32_t word = slot[j] | (last ? kCandLast : 0u);
+            if (j == 0) cand.first()[gid] = word;  // (the first candidate's distance is never looked at)
+            else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(tested));
 }
@@ -780,8 +782,11 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 const bool entry_stored = more && cursor < kCandMax;
                 const float4 ro = ray_o[(more || h_hit) ? rid : 0u];
                 const float4 rd = ray_d[more ? rid : 0u];
-                const uint2 e = cand.e[entry_stored ? static_cast<size_t>(cursor) * cand.stride + rid : 0u];
-                uint32_t e_x = e.x, e_y = e.y, rd_w = __float_as_uint(rd.w);
+                // (the first candidate is a slot word of its own; a ray that has no hit yet enters it whatever its distance)
+                const bool first_entry = cursor == 0u;
+                const uint32_t e0 = cand.first()[(entry_stored && first_entry) ? rid : 0u];
+                const uint2 e = cand.e[(entry_stored && !first_entry) ? static_cast<size_t>(cursor) * cand.stride + rid : 0u];
+                uint32_t e_x = first_entry ? 0u : e.x, e_y = first_entry ? e0 : e.y, rd_w = __float_as_uint(rd.w);
                 // (an empty statement that "uses" the entry and the ray's flag word here: without it the compiler moves each
                 // word's load down to the branch that looks at it, behind the wait for the ray, and the round trips are in
                 // a row again)
