@@ -20,8 +20,14 @@ constexpr int kTopNodes4 = 192;      // likewise for the four-wide form (also 64
 #ifndef PT_XFORM_LDS7
 #define PT_XFORM_LDS7 12
 #endif
-constexpr int kStackLds7 = 10;
-constexpr int kTopNodes7 = 176;
+#ifndef PT_STACK_LDS7
+#define PT_STACK_LDS7 10
+#endif
+#ifndef PT_TOP_NODES7
+#define PT_TOP_NODES7 176
+#endif
+constexpr int kStackLds7 = PT_STACK_LDS7;
+constexpr int kTopNodes7 = PT_TOP_NODES7;
 constexpr uint32_t kXformLds7 = PT_XFORM_LDS7;
 constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
 constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
