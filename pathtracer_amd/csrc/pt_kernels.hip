@@ -1244,7 +1244,11 @@ __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
     if (threadIdx.x < n_quarters) s_objects[threadIdx.x] = reinterpret_cast<const float4*>(sc.objects)[threadIdx.x];
     __syncthreads();
 }
+// ALL_LDS: the scene has at most kObjLds objects, so every record is in the LDS copy.  The pointer is then known to be an
+// LDS address: its reads wait for the LDS counter only, instead of a flat read's wait for every load in flight.
+template <bool ALL_LDS = false>
 __device__ __forceinline__ const DevObject* object_record(const SceneDev& sc, uint32_t object) {
+    if (ALL_LDS) return reinterpret_cast<const DevObject*>(s_objects) + (object < kObjLds ? object : 0u);
     return (object < kObjLds) ? reinterpret_cast<const DevObject*>(s_objects) + object : sc.objects + object;
 }
 __device__ __forceinline__ float4 texel8(const SceneDev& sc, uint32_t word, bool srgb) {
@@ -1374,9 +1378,10 @@ struct ShadePoint {
     const DevObject* obj;
 };
 // get_vertex_data + interpolate_vertex_data + convert_normals_to_world_space (ray_program.cc:75-101)
+template <bool ALL_LDS = false>
 __device__ __forceinline__ ShadePoint fetch_point(const SceneDev& sc, uint32_t object, uint32_t tri, float A, float B) {
     ShadePoint sp;
-    sp.obj = object_record(sc, object);
+    sp.obj = object_record<ALL_LDS>(sc, object);
     const float4* rec = sc.corners + static_cast<size_t>(sp.obj->tri_base + tri / 3u) * 9u;  // tri = 3 * triangle number
     const VertexD v1 = load_vertex(rec), v2 = load_vertex(rec + 3), v3 = load_vertex(rec + 6);
     const float C = 1.0f - A - B;
@@ -1548,7 +1553,7 @@ __device__ __forceinline__ float lobe_weight(f3 p) {
     return ((w > 0.0f) && (w < kInfF)) ? w : 0.0f;
 }
 
-template <bool SINGLE>
+template <bool SINGLE, bool ALL_LDS>
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
     // Three stages, so that no spawned ray has to wait in registers for the others:
@@ -1593,7 +1598,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         } else {
             const bool backface = (h1 & 0x40000000u) != 0;
             const float4 h0 = hits.h0[i];  // written for hits only
-            ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
+            ShadePoint sp = fetch_point<ALL_LDS>(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             sp.p.position = xform(sp.obj->model, sp.p.position, 1.0f);
             normals_to_world(sp);
             const DevMaterial& mat = sp.obj->mat;
@@ -1918,13 +1923,14 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
     const dim3 grid(blocks_for(n)), block(kBlock);
     if (program == 1)
         PT_LAUNCH(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
-    else if (program == 2 && single_path)
-        PT_LAUNCH(shade_pbr_kernel<true>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
-                           out, out_count, fb);
-    else if (program == 2)
-        PT_LAUNCH(shade_pbr_kernel<false>, dim3((n + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, st, sc, rays, n, hits,
-                           out, out_count, fb);
-    else
+    else if (program == 2) {
+        const dim3 g((n + kShadeBlock - 1) / kShadeBlock), b(kShadeBlock);
+        const bool all_lds = sc.n_instances <= kObjLds;  // every object record is in the kernel's LDS copy
+        if (single_path && all_lds) PT_LAUNCH((shade_pbr_kernel<true, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
+        else if (single_path) PT_LAUNCH((shade_pbr_kernel<true, false>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
+        else if (all_lds) PT_LAUNCH((shade_pbr_kernel<false, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
+        else PT_LAUNCH((shade_pbr_kernel<false, false>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
+    } else
         PT_LAUNCH(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
 }
 void launch_clear(hipStream_t st, float* p, uint64_t n) {
