@@ -64,6 +64,7 @@ constexpr uint32_t kTlasLds = 512;       // nodes of that tree kept in LDS by th
 struct CandQueue {
     uint2* e;
     uint32_t stride;
+    uint32_t* h1 = nullptr;  // the launch's hit flag words (set by launch_extend_persistent): cleared by the instance pass
     __host__ __device__ uint32_t* first() const { return reinterpret_cast<uint32_t*>(e); }
 };
 static_assert(kCandMax >= 2, "the continuation pass reads the last entry with its distance");

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
         if (j == 0 || slot[j] != PT_NO_NODE) {
             const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
             const uint32_t word = slot[j] | (last ? kCandLast : 0u);
+            if (j == 0) cand.h1[gid] = 0u;  // "no hit" until the traversal kernel accepts one: a miss then writes nothing
             if (j == 0) cand.first()[gid] = word;  // (the first candidate's distance is never looked at)
             else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(kBlock) void tlas_tree_kernel(SceneDev sc, const fl
         if (j == 0 || slot[j] != PT_NO_NODE) {
             const bool last = (j + 1 < kCandMax) && (slot[j] != PT_NO_NODE) && (slot[j + 1 < kCandMax ? j + 1 : j] == PT_NO_NODE);
             const uint32_t word = slot[j] | (last ? kCandLast : 0u);
+            if (j == 0) cand.h1[gid] = 0u;  // "no hit" until the traversal kernel accepts one: a miss then writes nothing
             if (j == 0) cand.first()[gid] = word;  // (the first candidate's distance is never looked at)
             else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
@@ -829,8 +831,9 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                     }
                 }
                 if (enter_slot == PT_NO_NODE) {  // the ray is done here
-                    // a miss is one word: nothing reads the distance / barycentrics record of a ray whose flag word says "no hit"
-                    if (!(flags & F_BHIT)) hit1[rid] = 0u;
+                    // a miss writes nothing: the instance pass has set every flag word of the launch to "no hit" (one streamed
+                    // word per ray instead of a scattered one that leaves the L2 as a partial sector), and nothing reads the
+                    // distance / barycentrics record of a ray whose flag word says so
                     if (deferred) overflow[1u + atomicAdd(overflow, 1u)] = rid;
                     cur = PT_IDLE;
                 }
@@ -1886,6 +1889,7 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
             g_launch_kernel = "hipMemsetAsync of the traversal cursors";
         }
     const dim3 g_all(blocks_for(n)), g_p(grid), g_c(std::min<uint32_t>(n_blocks, 64u)), b(kBlock);
+    cand.h1 = hits.h1;
     if (counters) {
         if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         else PT_LAUNCH(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
