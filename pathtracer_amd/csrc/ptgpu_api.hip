@@ -656,7 +656,7 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
     if (const char* m = std::getenv("PTGPU_EXTEND")) ctx->persistent = std::strcmp(m, "simple") != 0;
     if (const char* k = std::getenv("PTGPU_CHUNK")) {
         long v = std::atol(k);
-        if (v >= 1024) ctx->chunk = static_cast<uint32_t>(std::min<long>(v, 1l << 26)) & ~63u;
+        if (v >= 1024) ctx->chunk = static_cast<uint32_t>(std::min<long>(v, 1l << 28)) & ~63u;
     }
     *out = ctx.release();
     return PTGPU_OK;
