@@ -126,6 +126,7 @@ struct SceneDev {
     const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
     uint32_t n_top_nodes4;        // likewise for nodes4
     uint32_t seven_waves;         // the four-wide traversal kernel runs in its seven-workgroups-per-CU form (shorter LDS stack)
+    uint32_t leaf_vote;           // weight of the lanes that hold a leaf when the traversal kernel chooses its next phase (1 or 4)
     int32_t env_w, env_h;
     float env_rot;
 };

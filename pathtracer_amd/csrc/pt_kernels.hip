@@ -364,6 +364,22 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #else
 #define PT_BURST_UNROLL
 #endif
+// a burst of steps ends when fewer than NUM / DEN of the lanes it started with still hold a node (a leaf)
+#ifndef PT_KEEP_NUM
+#define PT_KEEP_NUM 1u
+#endif
+#ifndef PT_KEEP_DEN
+#define PT_KEEP_DEN 2u
+#endif
+#ifndef PT_LEAF_KEEP_NUM
+#define PT_LEAF_KEEP_NUM 1u
+#endif
+#ifndef PT_LEAF_KEEP_DEN
+#define PT_LEAF_KEEP_DEN 2u
+#endif
+#ifndef PT_LEAF_BURST
+#define PT_LEAF_BURST PT_BURST
+#endif
 #ifndef PT_RAY_BLOCK
 #define PT_RAY_BLOCK 128u
 #endif
@@ -629,6 +645,11 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
     TraceCount cnt{};
     static_assert(kTopNodes4 <= kTopNodes && sizeof(Node4) == sizeof(NodeQ), "the four-wide node cache fits the same LDS array");
     static_assert(!SEVEN || WIDE, "the seven-wave budget is for the four-wide kernel");
+    // Which phase runs when lanes wait at nodes and at leaves: node steps while (lanes at nodes) >= (lanes at leaves) * leaf_vote.
+    // With a weight of 4 a leaf step runs for as few as a fifth of the traversing lanes: the lanes it releases go back to the node
+    // steps, which are most of the work of a deep closest-hit traversal (readme frame: traversal -1.5 %, binary nodes -2.2 %,
+    // 10 M-triangle frame -1.9 %); short traversals and any-hit rays, which end at their leaf, run 1-2 % slower that way and keep 1.
+    const uint32_t leaf_vote = sc.leaf_vote;
     const uint32_t n_top_scene = WIDE ? sc.n_top_nodes4 : sc.n_top_nodes;
     const uint32_t n_top = n_top_scene < static_cast<uint32_t>(kTop) ? n_top_scene : static_cast<uint32_t>(kTop);
     {
@@ -885,7 +906,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 sp = 0;
                 cur = WIDE ? xf.root4 : xf.root;
             }
-        } else if (n_inner && n_inner >= n_leaf) {
+        } else if (n_inner && n_inner >= n_leaf * leaf_vote) {
             // ================= inner-node steps for the lanes that hold a node =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
@@ -952,7 +973,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 }
                 if (++burst >= (WIDE ? PT_WIDE_BURST : PT_BURST)) { if (COUNT) tally(2, burst); break; }
                 const uint32_t still = __popcll(__ballot(is_node(cur)));
-                if (still * 2u < n_inner) { if (COUNT) tally(2, burst); break; }
+                if (still * PT_KEEP_DEN < n_inner * PT_KEEP_NUM) { if (COUNT) tally(2, burst); break; }
             }
         } else if (n_leaf) {
             // ================= triangle tests for the lanes that hold a leaf =================
@@ -1021,9 +1042,9 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                         pop_to(top);
                     }
                 }
-                if (++burst >= PT_BURST) { if (COUNT) tally(3, burst); break; }
+                if (++burst >= PT_LEAF_BURST) { if (COUNT) tally(3, burst); break; }
                 const uint32_t still = __popcll(__ballot(is_leaf(cur)));
-                if (still * 2u < n_leaf) { if (COUNT) tally(3, burst); break; }
+                if (still * PT_LEAF_KEEP_DEN < n_leaf * PT_LEAF_KEEP_NUM) { if (COUNT) tally(3, burst); break; }
             }
         } else {
             break;  // no live lane: either the cursor is exhausted or (unreachable) all 64 lanes just refilled nothing

@@ -1285,6 +1285,16 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.n_tlas = static_cast<uint32_t>(tlas.size());
     sc.n_top_nodes4 = n_top4;
     sc.seven_waves = seven_waves ? 1u : 0u;
+    {   // deep closest-hit traversals (large scenes, every program but ambient occlusion with its any-hit rays) give leaves the
+        // heavier vote in the traversal kernel's choice of phase; PTGPU_LEAF_VOTE=<1..16> overrides
+        uint64_t instanced = 0;
+        for (uint32_t i = 0; i < model->n_objects; ++i) instanced += model->meshes[model->objects[i].mesh_index].n_indices / 3;
+        sc.leaf_vote = (s.program_mode != PTGPU_PROGRAM_AO && instanced >= 500000) ? 4u : 1u;
+        if (const char* v = std::getenv("PTGPU_LEAF_VOTE")) {
+            const long k = std::atol(v);
+            if (k >= 1 && k <= 16) sc.leaf_vote = static_cast<uint32_t>(k);
+        }
+    }
     c->persist_blocks = 0;  // the resident grid depends on the kernel form: sized again at the next render
     sc.env_w = env_w;
     sc.env_h = env_h;
