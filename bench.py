@@ -292,9 +292,15 @@ def main() -> None:
             bytes_per_ray = V * 64 + T * 48 + E * 128 + (E + 1) * 8 + 32 + 20
             tlas_bytes_per_ray = I * 64 + 32 + (E + 1) * 8
             traverse_s = traverse_ms / 1e3
-            kernel_name = "traverse_kernel<false, false>" if args.binary_nodes else "traverse_kernel<false, true>"
-            if not args.binary_nodes and getattr(st, "traverse_workgroups_per_cu", 6) == 7:
-                kernel_name = "traverse_kernel7<false>"  # the form for scenes that the caches hold (seven workgroups per CU)
+            # the kernel's name as the profiler prints it: <counting, four-wide nodes, every instance transform in LDS>
+            seven = not args.binary_nodes and getattr(st, "traverse_workgroups_per_cu", 6) == 7  # the form for scenes the caches hold
+            xf_lds = "true" if len(model.objects) <= (12 if seven else 16) else "false"
+            if seven:
+                kernel_name, legacy_name = f"traverse_kernel7<false, {xf_lds}>", "traverse_kernel7<false>"
+            elif args.binary_nodes:
+                kernel_name, legacy_name = f"traverse_kernel<false, false, {xf_lds}>", "traverse_kernel<false, false>"
+            else:
+                kernel_name, legacy_name = f"traverse_kernel<false, true, {xf_lds}>", "traverse_kernel<false, true>"
             launches = max(extend_launches, 1)
             avg_launch_s = traverse_s / launches
             rays_per_launch = rays / launches
@@ -310,7 +316,8 @@ def main() -> None:
             key = f"{args.config}/{'binary' if args.binary_nodes else 'wide'}"
             if os.path.exists(tpath):
                 entry = json.load(open(tpath)).get("configs", {}).get(key)
-                k = (entry or {}).get("kernels", {}).get(kernel_name)
+                kernels = (entry or {}).get("kernels", {})
+                k = kernels.get(kernel_name) or kernels.get(legacy_name)  # (profiles taken before the kernels had the last argument)
                 same_scene = entry and entry.get("scene") == f"{model.instanced_triangles()} triangles, {len(model.objects)} objects"
                 if k and same_scene and entry.get("bounces") == cfg["bounces"] and entry.get("resolution") == [w, h]:
                     measured = (k["fetch_bytes_per_ray"] + k["write_bytes_per_ray"]) * rays_per_launch

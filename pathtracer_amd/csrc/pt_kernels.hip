@@ -380,6 +380,9 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_LEAF_BURST
 #define PT_LEAF_BURST PT_BURST
 #endif
+#ifndef PT_XF_LDS
+#define PT_XF_LDS 1
+#endif
 #ifndef PT_RAY_BLOCK
 #define PT_RAY_BLOCK 128u
 #endif
@@ -622,7 +625,9 @@ __device__ __forceinline__ float box_entry_fast(float lox, float loy, float loz,
 enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u, F_LAST = 16u };  // F_LAST: the candidate list has no further entry
 // SEVEN: the LDS budget of seven workgroups per CU instead of six (a shorter LDS stack, fewer cached nodes and transforms),
 // for the kernel that is compiled for seven wavefronts per SIMD.
-template <bool COUNT, bool WIDE, bool SEVEN>
+// XF_LDS: every instance transform of the scene is in the kernel's LDS copy, so a transform is read with LDS instructions
+// (no work for the vector memory path's address unit, and its waits do not cover the loads from memory in flight).
+template <bool COUNT, bool WIDE, bool SEVEN, bool XF_LDS>
 __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* __restrict__ ray_o,
                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
@@ -660,6 +665,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
     }
     __syncthreads();
     auto xform_record = [&](uint32_t k) -> const DevXform& {
+        if (XF_LDS) return reinterpret_cast<const DevXform*>(s_xf)[k < kXf ? k : 0u];
         return (k < kXf) ? reinterpret_cast<const DevXform*>(s_xf)[k] : sc.xforms[k];
     };
 
@@ -1062,26 +1068,26 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 for (int k = 0; k < 6; ++k) atomicAdd(&counters->census[ph][k], static_cast<unsigned long long>(cnt.census[ph][k]));
     }
 }
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool XF_LDS = false>
 __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                  const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                  float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                  uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
                                                  uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                                  TraceCounters* counters) {
-    traverse_body<COUNT, WIDE, false>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+    traverse_body<COUNT, WIDE, false, XF_LDS>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 // The four-wide kernel at seven wavefronts per SIMD (72 registers, 22 KB of LDS per workgroup).  Scenes that the caches
 // hold are limited by the latency of a step, and a seventh wavefront hides more of it (2.5-4 % faster); scenes that are
 // limited by the gather path (the 10 M-triangle mesh) and the binary layout run 4-7 % slower that way and keep six.
-template <bool COUNT>
+template <bool COUNT, bool XF_LDS = false>
 __global__ __launch_bounds__(kBlock, 7) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
                                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
                                                               uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                                               TraceCounters* counters) {
-    traverse_body<COUNT, true, true>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+    traverse_body<COUNT, true, true, XF_LDS>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 
 // Continuation for rays with more than kCandMax candidate instances (a rarity: that many bounding volumes pierced
@@ -1908,7 +1914,7 @@ void launch_extend(hipStream_t st, const SceneDev& sc, RayQueue rays, uint32_t n
 }
 uint32_t extend_persistent_grid(int device, bool seven_waves) {
     int per_cu = 0, cus = 0;
-    const hipError_t e = seven_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel7<false>, kBlock, 0)
+    const hipError_t e = seven_waves ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel7<false, false>, kBlock, 0)
                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, traverse_kernel<false, false>, kBlock, 0);
     if (e != hipSuccess || per_cu < 1)
         per_cu = 2;
@@ -1945,11 +1951,21 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         if (sc.tlas) PT_LAUNCH(tlas_tree_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         else PT_LAUNCH(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
-        if (sc.nodes4 && sc.seven_waves)
-            PT_LAUNCH(traverse_kernel7<false>, g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+        // (the forms with the last argument set read the instance transforms from LDS only: scenes whose transforms all fit there)
+        if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= kXformLds7)
+            PT_LAUNCH((traverse_kernel7<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
                                stride, next_ray, overflow, counters);
+        else if (sc.nodes4 && sc.seven_waves)
+            PT_LAUNCH((traverse_kernel7<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.nodes4 && sc.n_instances <= kXformLds)
+            PT_LAUNCH((traverse_kernel<false, true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
         else if (sc.nodes4)
-            PT_LAUNCH((traverse_kernel<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+            PT_LAUNCH((traverse_kernel<false, true, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.n_instances <= kXformLds)
+            PT_LAUNCH((traverse_kernel<false, false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         else
             PT_LAUNCH((traverse_kernel<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
