@@ -383,6 +383,9 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_XF_LDS
 #define PT_XF_LDS 1
 #endif
+#ifndef PT_SEVEN_WAVES
+#define PT_SEVEN_WAVES 7  // wavefronts per SIMD the second form of the four-wide kernel is compiled for
+#endif
 #ifndef PT_RAY_BLOCK
 #define PT_RAY_BLOCK 128u
 #endif
@@ -1081,7 +1084,7 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
 // hold are limited by the latency of a step, and a seventh wavefront hides more of it (2.5-4 % faster); scenes that are
 // limited by the gather path (the 10 M-triangle mesh) and the binary layout run 4-7 % slower that way and keep six.
 template <bool COUNT, bool XF_LDS = false>
-__global__ __launch_bounds__(kBlock, 7) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
+__global__ __launch_bounds__(kBlock, PT_SEVEN_WAVES) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
                                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
@@ -1515,6 +1518,7 @@ __global__ __launch_bounds__(kBlock) void shade_raycast_kernel(SceneDev sc, RayQ
 // ---------------------------------------------------------------------------------------------
 // shade: AmbientOcclusion (ray_program.cc:172-225)
 // ---------------------------------------------------------------------------------------------
+template <bool ALL_LDS>  // every object record of the scene is in the LDS copy (see object_record)
 __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                           RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb,
                                                           uint32_t ao_samples) {
@@ -1535,7 +1539,7 @@ __global__ __launch_bounds__(kBlock) void shade_ao_kernel(SceneDev sc, RayQueue 
             add_radiance(fb, pid, f3{rp.x, rp.y, rp.z});  // miss: return the payload
         } else if (depth != 0) {
             const float4 h0 = hits.h0[i];  // written for hits only
-            ShadePoint sp = fetch_point(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
+            ShadePoint sp = fetch_point<ALL_LDS>(sc, h1 & 0x3fffffffu, __float_as_uint(h0.w), h0.y, h0.z);
             normals_to_world(sp);
             const DevMaterial& mat = sp.obj->mat;
             if ((h1 & 0x40000000u) && mat.double_sided) sp.p.normal = sp.p.normal * -1.0f;
@@ -1979,11 +1983,12 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path) {
     if (!n) return;
     const dim3 grid(blocks_for(n)), block(kBlock);
-    if (program == 1)
-        PT_LAUNCH(shade_ao_kernel, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
-    else if (program == 2) {
+    const bool all_lds = sc.n_instances <= kObjLds;  // every object record is in the kernel's LDS copy
+    if (program == 1) {
+        if (all_lds) PT_LAUNCH(shade_ao_kernel<true>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
+        else PT_LAUNCH(shade_ao_kernel<false>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
+    } else if (program == 2) {
         const dim3 g((n + kShadeBlock - 1) / kShadeBlock), b(kShadeBlock);
-        const bool all_lds = sc.n_instances <= kObjLds;  // every object record is in the kernel's LDS copy
         if (single_path && all_lds) PT_LAUNCH((shade_pbr_kernel<true, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
         else if (single_path) PT_LAUNCH((shade_pbr_kernel<true, false>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
         else if (all_lds) PT_LAUNCH((shade_pbr_kernel<false, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
