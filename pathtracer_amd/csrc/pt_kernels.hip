@@ -383,6 +383,9 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_XF_LDS
 #define PT_XF_LDS 1
 #endif
+#ifndef PT_CLAIM_STRADDLE
+#define PT_CLAIM_STRADDLE 1
+#endif
 #ifndef PT_SEVEN_WAVES
 #define PT_SEVEN_WAVES 7  // wavefronts per SIMD the second form of the four-wide kernel is compiled for
 #endif
@@ -886,18 +889,31 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
             if (!claim.exhausted) {
                 const unsigned long long m_free = __ballot(cur == PT_IDLE);
                 const uint32_t n_free = __popcll(m_free);
-                if (n_free && claim.next >= claim.end) claim = claim_block(claim, next_ray, n, lane);
-                const uint32_t avail = claim.end - claim.next;
                 const uint32_t rank = __popcll(m_free & lt_mask);
-                if (cur == PT_IDLE && rank < avail) {
-                    rid = claim.next + rank;
+                // What is left of the wavefront's block goes to the first free lanes; when that is not enough for all of
+                // them, the next block is claimed in the same pass and the other lanes start there — a lane left without a
+                // ray here would sit out every step until the next service pass.
+                const uint32_t rest_first = claim.next;
+                const uint32_t rest = claim.end - claim.next;
+                const bool claims = PT_CLAIM_STRADDLE ? (rest < n_free) : (n_free && rest == 0u);
+                if (claims) claim = claim_block(claim, next_ray, n, lane);
+                const uint32_t from_rest = claims ? rest : 0u;  // lanes served by what was left of the old block
+                const uint32_t avail = claim.end - claim.next;                            // rays left in the current block
+                uint32_t take = 0xffffffffu;
+                if (cur == PT_IDLE) {
+                    if (rank < from_rest) take = rest_first + rank;
+                    else if (rank - from_rest < avail) take = claim.next + (rank - from_rest);
+                }
+                if (take != 0xffffffffu) {
+                    rid = take;
                     cursor = 0;
                     flags = 0;
                     b_t = kInfF;
                     h_hit = false;
                     fresh = true;
                 }
-                claim.next += (n_free < avail) ? n_free : avail;
+                const uint32_t wanted = n_free - from_rest;  // (from_rest < n_free whenever it is not zero)
+                claim.next += (wanted < avail) ? wanted : avail;
             }
             if (fresh) pick(true);
             if (enter_slot != PT_NO_NODE) {
