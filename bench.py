@@ -294,9 +294,10 @@ def main() -> None:
             traverse_s = traverse_ms / 1e3
             # the kernel's name as the profiler prints it: <counting, four-wide nodes, every instance transform in LDS>
             seven = not args.binary_nodes and getattr(st, "traverse_workgroups_per_cu", 6) == 7  # the form for scenes the caches hold
-            xf_lds = "true" if len(model.objects) <= (12 if seven else 16) else "false"
-            if seven:
-                kernel_name, legacy_name = f"traverse_kernel7<false, {xf_lds}>", "traverse_kernel7<false>"
+            xf_lds = "true" if len(model.objects) <= (24 if seven else 16) else "false"
+            if seven:  # (its third argument: the form with 24 instead of 12 transforms in LDS)
+                xf_many = "true" if 12 < len(model.objects) <= 24 else "false"
+                kernel_name, legacy_name = f"traverse_kernel7<false, {xf_lds}, {xf_many}>", "traverse_kernel7<false>"
             elif args.binary_nodes:
                 kernel_name, legacy_name = f"traverse_kernel<false, false, {xf_lds}>", "traverse_kernel<false, false>"
             else:

@@ -29,6 +29,9 @@ constexpr int kTopNodes4 = 192;      // likewise for the four-wide form (also 64
 constexpr int kStackLds7 = PT_STACK_LDS7;
 constexpr int kTopNodes7 = PT_TOP_NODES7;
 constexpr uint32_t kXformLds7 = PT_XFORM_LDS7;
+// the seven-wave kernel's form for scenes with up to twice that many instances: all their transforms in LDS, fewer cached nodes
+constexpr int kTopNodes7Many = kTopNodes7 - 2 * static_cast<int>(kXformLds7);
+inline int top_nodes7_for(uint32_t n_instances) { return (n_instances > kXformLds7 && n_instances <= 2u * kXformLds7) ? kTopNodes7Many : kTopNodes7; }
 constexpr int kInstLds = 16;         // per-lane cached instance entry distances kept in LDS
 constexpr int kTile = 8;             // framebuffer / camera-ray tiles are 8x8 pixels = one wavefront
 

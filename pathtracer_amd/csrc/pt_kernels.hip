@@ -383,6 +383,9 @@ __global__ PT_EXTEND_BOUNDS void extend_kernel(SceneDev sc, const float4* __rest
 #ifndef PT_XF_LDS
 #define PT_XF_LDS 1
 #endif
+#ifndef PT_OBJ_LDS
+#define PT_OBJ_LDS 32  // object records in the shading kernels' LDS copy (256 B each; only as many as the scene has are copied)
+#endif
 #ifndef PT_CLAIM_STRADDLE
 #define PT_CLAIM_STRADDLE 1
 #endif
@@ -633,7 +636,8 @@ enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u, F_LAST = 16
 // for the kernel that is compiled for seven wavefronts per SIMD.
 // XF_LDS: every instance transform of the scene is in the kernel's LDS copy, so a transform is read with LDS instructions
 // (no work for the vector memory path's address unit, and its waits do not cover the loads from memory in flight).
-template <bool COUNT, bool WIDE, bool SEVEN, bool XF_LDS>
+// XF_MANY (seven-wave form only): twice the transforms in LDS, paid for with fewer cached nodes.
+template <bool COUNT, bool WIDE, bool SEVEN, bool XF_LDS, bool XF_MANY = false>
 __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* __restrict__ ray_o,
                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
@@ -641,8 +645,9 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                                               uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                               TraceCounters* counters) {
     constexpr int kStack = SEVEN ? kStackLds7 : kStackLds;
-    constexpr int kTop = SEVEN ? kTopNodes7 : kTopNodes;
-    constexpr uint32_t kXf = SEVEN ? kXformLds7 : kXformLds;
+    static_assert(!XF_MANY || (SEVEN && XF_LDS), "the larger transform table is a form of the seven-wave kernel");
+    constexpr int kTop = SEVEN ? (XF_MANY ? kTopNodes7Many : kTopNodes7) : kTopNodes;
+    constexpr uint32_t kXf = SEVEN ? (XF_MANY ? 2u * kXformLds7 : kXformLds7) : kXformLds;
     __shared__ uint32_t s_stack[kStack][kBlock];
     // The most visited nodes (the first of the node array), 64 bytes each, node after node.  Layouts that spread the
     // lanes' reads over more banks (quarter-major, 80-byte stride) measured 20-40 % slower for the whole kernel.
@@ -1099,14 +1104,14 @@ __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __re
 // The four-wide kernel at seven wavefronts per SIMD (72 registers, 22 KB of LDS per workgroup).  Scenes that the caches
 // hold are limited by the latency of a step, and a seventh wavefront hides more of it (2.5-4 % faster); scenes that are
 // limited by the gather path (the 10 M-triangle mesh) and the binary layout run 4-7 % slower that way and keep six.
-template <bool COUNT, bool XF_LDS = false>
+template <bool COUNT, bool XF_LDS = false, bool XF_MANY = false>
 __global__ __launch_bounds__(kBlock, PT_SEVEN_WAVES) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
                                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
                                                               uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                                               TraceCounters* counters) {
-    traverse_body<COUNT, true, true, XF_LDS>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+    traverse_body<COUNT, true, true, XF_LDS, XF_MANY>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 
 // Continuation for rays with more than kCandMax candidate instances (a rarity: that many bounding volumes pierced
@@ -1298,7 +1303,7 @@ __shared__ float s_srgb_lut[256];
 __shared__ float s_unorm_lut[256];
 // The first kObjLds object records (matrices + material, 256 B each) are read by nearly every hit: a copy in LDS takes
 // those reads (15 of a PBR hit's ~58 loads) off the vector memory path.
-constexpr uint32_t kObjLds = 16;
+constexpr uint32_t kObjLds = PT_OBJ_LDS;
 __shared__ float4 s_objects[kObjLds * (sizeof(DevObject) / 16)];
 __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
     static_assert(kBlock >= 256, "one table entry per thread (of the first 256)");
@@ -1307,7 +1312,7 @@ __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
         s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
     }
     const uint32_t n_quarters = (sc.n_instances < kObjLds ? sc.n_instances : kObjLds) * (sizeof(DevObject) / 16);
-    if (threadIdx.x < n_quarters) s_objects[threadIdx.x] = reinterpret_cast<const float4*>(sc.objects)[threadIdx.x];
+    for (uint32_t q = threadIdx.x; q < n_quarters; q += blockDim.x) s_objects[q] = reinterpret_cast<const float4*>(sc.objects)[q];
     __syncthreads();
 }
 // ALL_LDS: the scene has at most kObjLds objects, so every record is in the LDS copy.  The pointer is then known to be an
@@ -1974,6 +1979,9 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         // (the forms with the last argument set read the instance transforms from LDS only: scenes whose transforms all fit there)
         if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= kXformLds7)
             PT_LAUNCH((traverse_kernel7<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= 2u * kXformLds7)
+            PT_LAUNCH((traverse_kernel7<false, true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
                                stride, next_ray, overflow, counters);
         else if (sc.nodes4 && sc.seven_waves)
             PT_LAUNCH((traverse_kernel7<false, false>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,

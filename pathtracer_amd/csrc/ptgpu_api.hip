@@ -1088,7 +1088,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
             seven_waves = geometry_bytes <= (128ull << 20);
             if (const char* e = std::getenv("PTGPU_TRAVERSE_WAVES")) seven_waves = std::atoi(e) == 7;
         }
-        const size_t top_capacity4 = seven_waves ? ptd::kTopNodes7 : ptd::kTopNodes4;
+        const size_t top_capacity4 = seven_waves ? ptd::top_nodes7_for(static_cast<uint32_t>(table.instances.size())) : ptd::kTopNodes4;
         // the most visited wide nodes first (same estimate as for the binary nodes), kept in LDS by the kernel
         {
             struct Entry {
