@@ -463,19 +463,35 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
             // sorted insertion; strict '<' keeps table order among equal distances
             float ck = any_hit ? -static_cast<float>(k) : dist;
             uint32_t cs = k;
+            // The walk covers entries 0 .. wave_filled (uniform: nothing is stored beyond the longest list of the wavefront).
+            // One straight-line copy of the walk per length, chosen by a scalar branch: a loop that is left early makes the
+            // compiler move the sixteen list registers around at every way out.
+            auto walk = [&](auto steps) {
+                constexpr int kSteps = decltype(steps)::value;
 #pragma unroll
-            for (int j = 0; j < kCandMax; ++j) {
-                if (static_cast<uint32_t>(j) > wave_filled) break;  // (uniform) nothing is stored beyond the longest list
-                const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
-                const float tk = key[j];
-                const uint32_t ts = slot[j];
-                key[j] = sw ? ck : tk;
-                slot[j] = sw ? cs : ts;
-                ck = sw ? tk : ck;
-                cs = sw ? ts : cs;
+                for (int j = 0; j < kSteps; ++j) {
+                    const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
+                    const float tk = key[j];
+                    const uint32_t ts = slot[j];
+                    key[j] = sw ? ck : tk;
+                    slot[j] = sw ? cs : ts;
+                    ck = sw ? tk : ck;
+                    cs = sw ? ts : cs;
+                }
                 // only a lane whose list was the longest fills the entry at wave_filled (lanes that sit this instance out
                 // hold fewer entries than that already)
-                if (static_cast<uint32_t>(j) == wave_filled) grew = __ballot(slot[j] != PT_NO_NODE) != 0ull;
+                grew = __ballot(slot[kSteps - 1] != PT_NO_NODE) != 0ull;
+            };
+            static_assert(kCandMax == 8, "one case per list length");
+            switch (wave_filled) {
+                case 0: walk(std::integral_constant<int, 1>{}); break;
+                case 1: walk(std::integral_constant<int, 2>{}); break;
+                case 2: walk(std::integral_constant<int, 3>{}); break;
+                case 3: walk(std::integral_constant<int, 4>{}); break;
+                case 4: walk(std::integral_constant<int, 5>{}); break;
+                case 5: walk(std::integral_constant<int, 6>{}); break;
+                case 6: walk(std::integral_constant<int, 7>{}); break;
+                default: walk(std::integral_constant<int, 8>{}); grew = false; break;  // (a full list cannot grow)
             }
         }
         if (__ballot(grew) != 0ull) ++wave_filled;
@@ -667,7 +683,11 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
     // 10 M-triangle frame -1.9 %); short traversals and any-hit rays, which end at their leaf, run 1-2 % slower that way and keep 1.
     const uint32_t leaf_vote = sc.leaf_vote;
     const uint32_t n_top_scene = WIDE ? sc.n_top_nodes4 : sc.n_top_nodes;
+#ifdef PT_NO_TOP_NODES  // experiment: no node is served from LDS (the node loads are then plain global loads)
+    const uint32_t n_top = 0u * n_top_scene;
+#else
     const uint32_t n_top = n_top_scene < static_cast<uint32_t>(kTop) ? n_top_scene : static_cast<uint32_t>(kTop);
+#endif
     {
         const float4* src = WIDE ? reinterpret_cast<const float4*>(sc.nodes4) : reinterpret_cast<const float4*>(sc.nodes);
         for (uint32_t i = tid; i < n_top * 4u; i += kBlock) s_top[i] = src[i];
