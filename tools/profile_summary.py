@@ -53,7 +53,7 @@ for tag, scale in (("fetch", 1.0), ("write", 1.0)):
     for (k, c), v in sorted(acc.items()):
         print(f"{k:32s} {c:12s} dispatches {cnt[(k, c)]:7d} total_GB {v*1024*scale/1e9:10.3f} "
               f"per_launch_MB {v*1024*scale/cnt[(k, c)]/1e6:10.3f}")
-        if "_kernel<false" in k or "_kernel7<false" in k or k == "generate_kernel":
+        if "_kernel<false" in k or "_kernel7<false" in k or k.startswith("shade_") or k.startswith("generate_kernel"):
             # the counter passes render ONE frame: bytes / rays of that frame is the fabric traffic per ray
             traffic["kernels"].setdefault(k, {})[tag + "_bytes_per_ray"] = v * 1024 * scale / rays_of_pass[tag]
 for f in glob.glob(root + "/trace/**/*kernel_stats.csv", recursive=True):
