@@ -347,10 +347,11 @@ def main() -> None:
                             "note": "algorithmic bytes minus the node visits served from the LDS node cache, against the rate the "
                                     "vector L1s sustain for divergent 64-byte records read as four 16-byte loads back to back "
                                     "(tools/micro/gather_bench.hip)"},
-                "binding": "not HBM bandwidth.  Cache-resident scenes (readme, AO, material): instruction issue on a dependent chain "
-                           "of ~18 fetches per ray (vector pipe 56 % busy at 5.8 waves per SIMD, 18 % of wave time ready but not "
-                           "issued; +25 % node loads cost +3 %, -10 % vector instructions gave -3.8 %).  The 10 M-triangle stress scene: "
-                           "the L1 address unit (TA 94 % busy) with the fabric at ~0.95 of the measured random-64-byte-sector rate "
+                "binding": "not HBM bandwidth.  Cache-resident scenes (readme, AO, material): instruction issue and the L1 address unit "
+                           "on a dependent chain of ~17 fetches per ray (vector pipe 58 % busy at 6.7 waves per SIMD, 27 % of wave time "
+                           "ready but not issued, address unit 89 % busy; +25 % node loads cost +3 %, -10 % vector instructions gave "
+                           "-3.8 %, transforms read from LDS instead of through flat loads -1.5 %).  The 10 M-triangle stress scene: "
+                           "the L1 address unit (TA 97 % busy) with the fabric at ~0.95 of the measured random-64-byte-sector rate "
                            "(profiles/r02_counters_readme.txt, profiles/r02_counters_stress.txt, DESIGN.md section 3)",
                 "note": "frac = measured fabric bytes (FETCH_SIZE + WRITE_SIZE: L2 misses, served by the Infinity Cache or HBM) / "
                         "kernel time / 8 TB/s; algorithmic_* counts every visit as a fetch and may exceed the peak on "
