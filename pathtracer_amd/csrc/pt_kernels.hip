@@ -508,6 +508,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
             else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
+    if (COUNT && slot[0] == PT_NO_NODE) atomicAdd(&counters->census[1][1], 1ull);  // rays that touch no instance (an empty list)
 }
 
 // The same pass for scenes with many instances.  The reference tests every object's bound for every ray

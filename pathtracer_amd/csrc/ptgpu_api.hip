@@ -560,7 +560,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.wave_triangle_iterations = tc.wave_tri;
         out.nodes_from_lds = tc.census[1][0];
         if (std::getenv("PTGPU_VERBOSE")) {
-            std::fprintf(stderr, "[ptgpu] node visits served from LDS: %llu of %llu\n", tc.census[1][0], tc.nodes);
+            std::fprintf(stderr, "[ptgpu] node visits served from LDS: %llu of %llu; rays that touch no instance: %llu\n", tc.census[1][0], tc.nodes,
+                         tc.census[1][1]);
             static const char* names[4] = {"service", "-", "inner", "leaf"};
             for (int ph = 0; ph < 4; ++ph) {
                 const double steps = static_cast<double>(std::max<unsigned long long>(tc.census[ph][1], 1));
