@@ -324,6 +324,33 @@ def test_both_forms_of_the_wide_kernel_agree(materials):
         assert np.abs(i6 - i7).max() <= 2e-5 * max(1.0, float(np.abs(i6).max()))  # (the framebuffer's summation order is not fixed)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_phase_vote_of_the_traversal_kernel_changes_no_result(materials, wide):
+    """Which phase a traversal wavefront runs next (node steps or leaf steps) is decided by a vote in which the lanes at
+    leaves carry a weight chosen at scene load (1, or 4 for large scenes; PTGPU_LEAF_VOTE overrides).  It schedules the
+    lanes and nothing else: hit records, any-hit flags and ray counts are equal to the bit for every weight."""
+    rng = np.random.default_rng(11)
+    n = 30000
+    org = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    any_flags = np.ones(n, np.uint8)
+    w, h = 160, 96
+    model, env = materials
+    results = []
+    for vote in ("1", "4", "16"):
+        os.environ["PTGPU_LEAF_VOTE"] = vote
+        try:
+            g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=wide), w, h)
+        finally:
+            os.environ.pop("PTGPU_LEAF_VOTE", None)
+        _, st = H.gpu_render(g, w, h)
+        results.append((g.intersect_rays(org, d), g.intersect_rays(org, d, any_flags)["hit"], int(st.rays)))
+    for c, a, r in results[1:]:
+        exact, _ = H.hits_equal(results[0][0], c)
+        assert exact.all() and (a == results[0][1]).all() and r == results[0][2]
+
+
 @pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
 def test_random_soups_both_node_layouts(seed, offset, flat):
     """Unstructured triangle soups under random affine transforms, also far from the object-space origin (box planes and
