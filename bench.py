@@ -330,6 +330,25 @@ def main() -> None:
             # HBM peak.  It cannot exceed 1.  The algorithmic figure (every node / triangle visit counted as a fetch,
             # whichever cache served it) is kept beside it: it measures the work done, not a bound.
             achieved = (measured / avg_launch_s / 1e9) if measured else None
+            # The secondary bounds of the same kernel (vector ALU, L1 address unit), from the committed utilisation counter
+            # passes of this configuration (tools/counters_report.sh); null for configurations without such a pass.
+            secondary = None
+            cpath = os.path.join(ROOT, "profiles", {"readme_pbr": "r02_counters_readme.txt", "stress_4k": "r02_counters_stress.txt"}.get(args.config, ""))
+            if os.path.isfile(cpath):
+                import re
+                text = open(cpath).read()
+                at = text.find(f"== {kernel_name} ==")
+                if at >= 0:
+                    block = text[at:text.find("\n== ", at + 4) if text.find("\n== ", at + 4) > 0 else len(text)]
+                    def grab(pattern):
+                        m = re.search(pattern, block)
+                        return float(m.group(1)) if m else None
+                    secondary = {"valu_utilisation": grab(r"VALU utilisation \([^)]*\)\s+([0-9.]+)"),
+                                 "waves_per_simd": grab(r"mean waves per SIMD \([^)]*\)\s+([0-9.]+)"),
+                                 "wave_time_waiting": grab(r"wave time: waiting ([0-9.]+)"),
+                                 "address_unit_busy": grab(r"TA busy ([0-9.]+)"),
+                                 "l2_hit_rate": grab(r"L2: hit rate ([0-9.]+)"),
+                                 "source": os.path.relpath(cpath, ROOT) + " (rocprofv3 --pmc passes of the same configuration at a reduced sample count)"}
             line["roofline"] = {
                 "kernel": kernel_name,
                 "bound": "hbm",
@@ -353,6 +372,7 @@ def main() -> None:
                            "-3.8 %, transforms read from LDS instead of through flat loads -1.5 %).  The 10 M-triangle stress scene: "
                            "the L1 address unit (TA 97 % busy) with the fabric at ~0.95 of the measured random-64-byte-sector rate "
                            "(profiles/r02_counters_readme.txt, profiles/r02_counters_stress.txt, DESIGN.md section 3)",
+                "secondary": secondary,
                 "note": "frac = measured fabric bytes (FETCH_SIZE + WRITE_SIZE: L2 misses, served by the Infinity Cache or HBM) / "
                         "kernel time / 8 TB/s; algorithmic_* counts every visit as a fetch and may exceed the peak on "
                         "cache-resident scenes",
