@@ -12,8 +12,15 @@ example/scene.glb, which is not available.  `value` is whole-job Mrays/s (rays =
 calls, counted by the scheduler from its queue sizes); ms_per_step is the time to render the frame.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Ranks.  With WORLD_SIZE in the environment (torchrun) the process is one rank of that many, and `--gpus` must say the
+same number.  Without it, `--gpus N` > 1 makes this process a launcher: it starts N children of itself with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, before it has touched torch or the GPU, passes rank 0's
+line through and exits non-zero if any child does.  The line carries `n_ranks_seen`, the all-reduced count of ranks that
+took part, so a run that silently used fewer ranks than asked for cannot pass as N.
 """
 from __future__ import annotations
 
@@ -122,6 +129,54 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 8.0):
     return out
 
 
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """Start `n` ranks of this script (one per GPU) and wait for them.  The launcher itself never imports torch and never
+    touches a GPU: the children are fresh processes, started before anything here could have initialised a device.
+    Rank 0's stdout is passed through (the JSON line), the other ranks' stdout is dropped, stderr is shared.  Returns
+    the first non-zero exit status of any rank, else 0; when one rank fails the others are stopped."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    # the host tree build of every rank runs at the same time: share the cores instead of oversubscribing them n-fold
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+    build_threads = max(1, min(16, cores) // n)
+    children = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("PTGPU_BUILD_THREADS", str(build_threads))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, text=True,
+                                         stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+
+    def relay(pipe):  # rank 0's JSON line goes to stdout; whatever else a library printed there goes to stderr
+        for ln in pipe:
+            print(ln, end="", file=sys.stdout if ln.lstrip().startswith("{") else sys.stderr, flush=True)
+
+    import threading
+    reader = threading.Thread(target=relay, args=(children[0].stdout,), daemon=True)
+    reader.start()
+    status = 0
+    pending = dict(enumerate(children))
+    while pending:
+        for rank, ch in list(pending.items()):
+            rc = ch.poll()
+            if rc is None:
+                continue
+            del pending[rank]
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {rank} of {n} exited with status {rc}; stopping the others", file=sys.stderr, flush=True)
+                for other in pending.values():  # exactly the processes started above, by handle
+                    other.terminate()
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    return status
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +196,18 @@ def main() -> None:
                     help="traverse the binary nodes in the reference's visiting order instead of the four-wide quantised nodes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, form the process group, count them, print the line's rank fields and stop: "
+                         "checks the launch path on a machine without GPUs (PT_BENCH_BACKEND=gloo); renders nothing")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:  # this process is the launcher; it has not imported torch and never touches a GPU
+            raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher and the "
+                         f"command line disagree about the number of ranks; refusing to report one as the other")
 
     cfg = dict(CONFIGS[args.config])
     if args.spp:
@@ -161,18 +227,39 @@ def main() -> None:
 
     import torch
     import torch.distributed as dist
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N > 1 path on a one-GPU box
+    if args.rendezvous_only:
+        if os.environ.get("PT_BENCH_TEST_FAIL_RANK") == str(rank):  # (tests: one rank dies before the rendezvous)
+            raise SystemExit(3)
+        if world > 1:
+            dist.init_process_group(backend)
+        ones = torch.ones(1, dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "n_ranks_seen": int(ones.item()), "backend": backend,
+                              "build_threads_per_rank": os.environ.get("PTGPU_BUILD_THREADS")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rendering path has no CPU fallback")
     # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals only) ranks share devices
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
-    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")  # "gloo" rehearses the N > 1 path on a one-GPU box
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+
+    if world > 1 and "PTGPU_BUILD_THREADS" not in os.environ:
+        # every rank of the node builds the scene's trees at the same time: share the host's cores (torchrun sets
+        # LOCAL_WORLD_SIZE; this script's own launcher has set the variable already)
+        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+        cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+        os.environ["PTGPU_BUILD_THREADS"] = str(max(1, min(16, cores) // local_world))
 
     from pathtracer_amd.renderer import (AccelerationStructureType, Perspective, RayProgramMode, Renderer,
                                          RenderSettings)
@@ -235,7 +322,8 @@ def main() -> None:
     fence()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cuda")
+    # (the last entry counts the ranks that took part: every rank adds one)
+    tot = torch.tensor([elapsed, float(rays), float(samples), 1.0], dtype=torch.float64, device="cuda")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -243,6 +331,9 @@ def main() -> None:
         elapsed = float(mx[0])
     total_rays = float(tot[1])
     total_samples = float(tot[2])
+    n_ranks_seen = int(round(float(tot[3])))
+    if n_ranks_seen != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {n_ranks_seen} ranks took part")
 
     if rank == 0:
         ms_per_step = elapsed / max(args.steps, 1) * 1e3
@@ -251,6 +342,7 @@ def main() -> None:
             "value": round(total_rays / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),

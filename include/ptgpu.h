@@ -163,6 +163,29 @@ typedef struct ptgpu_settings {
  * triangle tests per ray.  Ignored with PTGPU_AS_NAIVE. */
 #define PTGPU_FLAG_WIDE_NODES 2u
 
+/* Tuning of a context; no counterpart in the reference.  Zero in a field means "the library's choice", which is what
+ * every measurement in this repository was taken with unless it says otherwise.  A new context starts from the
+ * PTGPU_* environment variables of the same names (PTGPU_CHUNK, PTGPU_POOL_GIB, PTGPU_TRAVERSE_WAVES, PTGPU_LEAF_VOTE,
+ * PTGPU_BUILD_THREADS, PTGPU_INTERSECT_CHUNK, PTGPU_PERSIST_BLOCKS, PTGPU_EXTEND=simple, PTGPU_WIDE_SPLITS=reference,
+ * PTGPU_WIDE_COLLAPSE=greedy, PTGPU_TLAS=linear, PTGPU_VERBOSE=1|2), read once in ptgpu_create so that measurement
+ * scripts can alternate settings around an unchanged caller; ptgpu_set_options replaces them. */
+typedef struct ptgpu_options {
+    uint32_t chunk_rays;      /* camera samples per batch, 1024 .. 2^28 (default 2^26): sizes the ray pools and the launches */
+    uint32_t pool_gib;        /* upper bound of each of the two ray pools in GiB, 1 .. 256 (default 32) */
+    uint32_t traverse_waves;  /* four-wide traversal kernel at 6 or 7 workgroups per CU (default: by the size of the geometry) */
+    uint32_t leaf_vote;       /* 1 .. 16: weight of lanes at leaves when the traversal kernel picks its phase (default: by scene) */
+    uint32_t build_threads;   /* host threads of the tree build, 1 .. 64 (default: one per core, at most 16) */
+    uint32_t intersect_chunk; /* rays per pass of ptgpu_intersect_rays (default 4 Mi) */
+    uint32_t persist_blocks;  /* resident workgroups of the traversal kernel (default: occupancy x compute units) */
+    uint32_t flags;           /* PTGPU_OPT_* */
+} ptgpu_options;
+#define PTGPU_OPT_EXTEND_SIMPLE 1u      /* one ray per lane instead of the persistent traversal kernel (cross-check) */
+#define PTGPU_OPT_REFERENCE_SPLITS 2u   /* four-wide nodes collapsed from the reference's tree instead of the tuned one */
+#define PTGPU_OPT_GREEDY_COLLAPSE 4u    /* four-wide collapse: pull up the largest child instead of the optimal choice */
+#define PTGPU_OPT_LINEAR_TLAS 8u        /* every ray tests every instance bound, however many instances */
+#define PTGPU_OPT_VERBOSE 16u           /* diagnostics on stderr */
+#define PTGPU_OPT_VERBOSE_LAUNCHES 32u  /* one line per launch on stderr */
+
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */
 typedef struct ptgpu_hit {
@@ -224,11 +247,27 @@ const char* ptgpu_last_error(const ptgpu_ctx* ctx); /* ctx may be NULL: last cre
 int ptgpu_set_render_settings(ptgpu_ctx* ctx, const ptgpu_settings* settings);
 int ptgpu_get_render_settings(const ptgpu_ctx* ctx, ptgpu_settings* out);
 
+/* Takes effect at the next ptgpu_load_scene (build and kernel-form choices) or the next render (chunk, pools). */
+int ptgpu_set_options(ptgpu_ctx* ctx, const ptgpu_options* options);
+int ptgpu_get_options(const ptgpu_ctx* ctx, ptgpu_options* out);
+
 /* Renderer::load_scene (src/renderer.cc:41-64): builds the two-level
  * acceleration structure on the host exactly like BVH_AS::BVH_AS
  * (src/acceleration_structure.cc:352-536), flattens it to the device layout
  * and uploads geometry, materials, textures and the environment map. */
 int ptgpu_load_scene(ptgpu_ctx* ctx, const ptgpu_model* model, const ptgpu_envmap* env);
+
+/* The scene of another context, copied device to device (over xGMI between two GPUs of a node): the reference builds
+ * its acceleration structure once per Renderer::load_scene (src/renderer.cc:41-64), and a renderer that drives several
+ * GPUs should too — ptgpu_load_scene on the first context, this call on the others.  `ctx` ends up as if
+ * ptgpu_load_scene had been called on it with the source's model, environment and scene settings (acceleration
+ * structure type, leaf size, program, wide-node flag, environment rotation are taken over; samples, bounces, seed,
+ * sample / tile subset stay its own).  The source must not be rendering or loading during the call. */
+int ptgpu_load_scene_from(ptgpu_ctx* ctx, const ptgpu_ctx* source);
+
+/* Acceleration-structure builds (host or device side) this process has completed: one per ptgpu_load_scene,
+ * none per ptgpu_load_scene_from. */
+uint64_t ptgpu_host_build_count(void);
 
 /* Renderer::update_camera_transform_state (src/renderer.cc:27-39).
  * aspect <= 0 selects the reference default 1.7777778, zfar <= 0 selects 1000. */

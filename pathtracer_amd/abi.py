@@ -113,6 +113,15 @@ class Stats(C.Structure):
     ]
 
 
+class Options(C.Structure):
+    """``ptgpu_options``: tuning of a context; zero fields mean the library's choice."""
+    _fields_ = [("chunk_rays", C.c_uint32), ("pool_gib", C.c_uint32), ("traverse_waves", C.c_uint32), ("leaf_vote", C.c_uint32),
+                ("build_threads", C.c_uint32), ("intersect_chunk", C.c_uint32), ("persist_blocks", C.c_uint32), ("flags", C.c_uint32)]
+
+
+OPT_EXTEND_SIMPLE, OPT_REFERENCE_SPLITS, OPT_GREEDY_COLLAPSE, OPT_LINEAR_TLAS, OPT_VERBOSE, OPT_VERBOSE_LAUNCHES = 1, 2, 4, 8, 16, 32
+
+
 class BvhInfo(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("min_depth", C.c_uint32), ("max_depth", C.c_uint32), ("mean_depth", C.c_float),
@@ -156,7 +165,11 @@ def declare_ptgpu(lib: C.CDLL) -> None:
         "ptgpu_last_error": (C.c_char_p, [vp]),
         "ptgpu_set_render_settings": (C.c_int, [vp, P(Settings)]),
         "ptgpu_get_render_settings": (C.c_int, [vp, P(Settings)]),
+        "ptgpu_set_options": (C.c_int, [vp, P(Options)]),
+        "ptgpu_get_options": (C.c_int, [vp, P(Options)]),
         "ptgpu_load_scene": (C.c_int, [vp, P(Model), P(Envmap)]),
+        "ptgpu_load_scene_from": (C.c_int, [vp, vp]),
+        "ptgpu_host_build_count": (C.c_uint64, []),
         "ptgpu_update_camera_transform_state": (C.c_int, [vp, c_float_p, c_float_p, c_float_p, C.c_float, C.c_float,
                                                           C.c_float, C.c_float]),
         "ptgpu_set_camera_raw": (C.c_int, [vp, c_float_p, c_float_p]),
@@ -185,5 +198,5 @@ PTGPU_SYMBOLS = [
     "ptgpu_load_scene", "ptgpu_update_camera_transform_state", "ptgpu_set_camera_raw", "ptgpu_get_camera_raw",
     "ptgpu_get_scene_bound", "ptgpu_render_frame", "ptgpu_render_frame_sums", "ptgpu_resolve_sums",
     "ptgpu_render_counted", "ptgpu_render_hits", "ptgpu_intersect_rays", "ptgpu_intersect_rays_static", "ptgpu_get_bvh_info",
-    "ptgpu_subsample_positions",
+    "ptgpu_subsample_positions", "ptgpu_set_options", "ptgpu_get_options", "ptgpu_load_scene_from", "ptgpu_host_build_count",
 ]

@@ -215,7 +215,7 @@ uint32_t choose_split_tuned(std::vector<ptd::DevTri>& tris, uint32_t begin, uint
         const float scale = static_cast<float>(kBins) / (chi[a] - clo[a]);
         std::array<Bin, kBins> bins;
         for (int i = 0; i < n; ++i) {
-            const int b = std::clamp(static_cast<int>((centroid3(first[i], a) - clo[a]) * scale), 0, kBins - 1);
+            const int b = std::clamp(to_int_like_x86((centroid3(first[i], a) - clo[a]) * scale), 0, kBins - 1);
             ++bins[b].n;
             bins[b].box.add_box(tri_box(first[i]));
         }
@@ -247,7 +247,7 @@ uint32_t choose_split_tuned(std::vector<ptd::DevTri>& tris, uint32_t begin, uint
     if (best_axis < 0) return begin + static_cast<uint32_t>(n / 2);  // every centroid in one place
     const float lo = clo[best_axis];
     ptd::DevTri* mid = std::partition(first, first + n, [=](const ptd::DevTri& t) {
-        return std::clamp(static_cast<int>((centroid3(t, best_axis) - lo) * best_scale), 0, kBins - 1) < best_bin;
+        return std::clamp(to_int_like_x86((centroid3(t, best_axis) - lo) * best_scale), 0, kBins - 1) < best_bin;
     });
     return begin + static_cast<uint32_t>(mid - first);
 }
@@ -352,7 +352,7 @@ void collect_info(MeshTree& t, uint32_t n_real_tris) {  // collect_tree_info, :5
 }
 
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
-                     bool single_leaf, bool tuned, MeshTree& out) {
+                     bool single_leaf, bool tuned, MeshTree& out, unsigned build_threads) {
     out.nodes.clear();
     out.tris.clear();
     const uint32_t n_tris = n_indices / 3;
@@ -388,8 +388,7 @@ void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint
     // numbering of the nodes differs (top part first, then the subtrees).
     std::vector<Task> deferred;
     const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    const char* env = std::getenv("PTGPU_BUILD_THREADS");
-    const unsigned n_threads = env ? static_cast<unsigned>(std::max(1, std::atoi(env))) : hw;
+    const unsigned n_threads = build_threads ? std::min(build_threads, 64u) : hw;
     const uint32_t defer_below = (n_threads > 1 && n_tris >= (1u << 16)) ? std::max<uint32_t>(n_tris / (n_threads * 8u), max_leaf) : 0u;
     build_range(out.tris, Task{0u, n_tris, PT_NO_NODE, false}, max_leaf, tuned, out.nodes, &out.root, defer_below, &deferred);
     if (!deferred.empty()) {

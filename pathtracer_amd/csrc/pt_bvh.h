@@ -29,8 +29,10 @@ struct MeshTree {
 // `tuned_splits` leaves the reference's tree for one of lower expected cost (bins over the centroid range, exact
 // right-hand sums, every split position tried in small ranges): for the four-wide nodes, which do not keep the
 // reference's visiting order anyway.  Same closest hits, up to ties in distance.
+// `build_threads`: host threads that build independent subtrees of a large mesh (0 = one per core, at most 16); the tree
+// does not depend on it.
 void build_mesh_tree(const ptgpu_vertex* vertices, const uint32_t* indices, uint32_t n_indices, uint32_t max_leaf,
-                     bool single_leaf, bool tuned_splits, MeshTree& out);
+                     bool single_leaf, bool tuned_splits, MeshTree& out, unsigned build_threads = 0);
 
 // Device-side alternative (pt_lbvh.hip): a linear BVH over Morton-ordered triangles, built on the GPU of the current
 // device and read back into the same structure.  Different tree, same closest hits (up to ties in distance).

@@ -768,6 +768,9 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
             } else {  // an infinite inverse direction: planes decoded, exact select forms
                 auto entry = [&](int k) {
                     const int sh = 8 * k;
+                    // (an unused slot holds an inverted box; this test is symmetric in a slab's two planes and would take
+                    // it for a box that spans the node, so such a slot is skipped here explicitly)
+                    if (((lqx >> sh) & 0xffu) > ((hqx >> sh) & 0xffu)) return kInfF;
                     bool hh;
                     float dd;
                     box_test(q0.x + q0.w * static_cast<float>((lqx >> sh) & 0xffu), q0.y + q1.x * static_cast<float>((lqy >> sh) & 0xffu),
@@ -779,7 +782,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 d0 = entry(0); d1 = entry(1); d2 = entry(2); d3 = entry(3);
             }
             // (a node with fewer than four children has its unused slots filled with an inverted box around a leaf that holds
-            // one degenerate triangle, so no slot needs an "exists" test: see the conversion in ptgpu_load_scene)
+            // one degenerate triangle, so the fast path needs no "exists" test: see collapse_to_wide in pt_scene_build.cc)
             uint32_t r0 = __float_as_uint(rr.x), r1 = __float_as_uint(rr.y), r2 = __float_as_uint(rr.z), r3 = __float_as_uint(rr.w);
             auto order = [](float& da, uint32_t& ra, float& db, uint32_t& rb) {
                 const bool swap = db < da;

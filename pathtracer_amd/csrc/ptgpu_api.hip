@@ -23,6 +23,7 @@
 #include "ptgpu.h"
 #include "pt_bvh.h"
 #include "pt_kernels.h"
+#include "pt_scene_build.h"
 
 namespace {
 
@@ -169,6 +170,8 @@ struct ptgpu_ctx {
     ptgpu_settings settings{};        // current
     ptgpu_settings scene_settings{};  // as of the last load_scene (AS type, leaf size, program, env rotation)
     bool scene_loaded = false, camera_set = false;
+    ptgpu_options options{};          // tuning (ptgpu_set_options); zero fields mean "the library's choice"
+    bool has_nodes4 = false;          // the loaded scene carries four-wide nodes
 
     // scene
     DevBuf nodes, nodes4, tlas, tris, instances, xforms, objects, corners, texels, env, lut;
@@ -235,9 +238,43 @@ int upload(ptgpu_ctx* c, DevBuf& buf, const T* src, size_t n) {
     return PTGPU_OK;
 }
 
-float srgb_to_linear_host(float ch) {  // cpu_framebuffer.h:21-27
-    if (ch <= 0.04045f) return ch / 12.92f;
-    return std::pow((ch + 0.055f) / 1.055f, 2.4f);
+// A new context's options start from PTGPU_* environment variables: a convenience for the A/B tools (tools/ab_*.sh),
+// which alternate settings on one machine without touching the caller.  This is the one place the library reads them;
+// everything else reads ctx->options, and ptgpu_set_options replaces what was found here.
+ptgpu_options options_from_environment() {
+    ptgpu_options o{};
+    auto number = [](const char* name, long lo, long hi) -> uint32_t {
+        const char* v = std::getenv(name);
+        if (!v || !*v) return 0u;
+        const long k = std::atol(v);
+        return (k >= lo && k <= hi) ? static_cast<uint32_t>(k) : 0u;
+    };
+    auto is = [](const char* name, const char* value) {
+        const char* v = std::getenv(name);
+        return v && std::strcmp(v, value) == 0;
+    };
+    o.chunk_rays = number("PTGPU_CHUNK", 1024, 1l << 28);
+    o.pool_gib = number("PTGPU_POOL_GIB", 1, 256);
+    o.traverse_waves = number("PTGPU_TRAVERSE_WAVES", 6, 7);
+    o.leaf_vote = number("PTGPU_LEAF_VOTE", 1, 16);
+    o.build_threads = number("PTGPU_BUILD_THREADS", 1, 64);
+    o.intersect_chunk = number("PTGPU_INTERSECT_CHUNK", 1, 1l << 30);
+    o.persist_blocks = number("PTGPU_PERSIST_BLOCKS", 1, 1 << 20);
+    if (is("PTGPU_EXTEND", "simple")) o.flags |= PTGPU_OPT_EXTEND_SIMPLE;
+    if (is("PTGPU_WIDE_SPLITS", "reference")) o.flags |= PTGPU_OPT_REFERENCE_SPLITS;
+    if (is("PTGPU_WIDE_COLLAPSE", "greedy")) o.flags |= PTGPU_OPT_GREEDY_COLLAPSE;
+    if (is("PTGPU_TLAS", "linear")) o.flags |= PTGPU_OPT_LINEAR_TLAS;
+    const uint32_t verbose = number("PTGPU_VERBOSE", 1, 9);
+    if (verbose >= 1) o.flags |= PTGPU_OPT_VERBOSE;
+    if (verbose >= 2) o.flags |= PTGPU_OPT_VERBOSE_LAUNCHES;
+    return o;
+}
+void apply_options(ptgpu_ctx* c) {
+    const bool persistent = !(c->options.flags & PTGPU_OPT_EXTEND_SIMPLE);
+    if (persistent != c->persistent) c->scene_loaded = false;  // the loaded scene was laid out for the other kernel
+    c->persistent = persistent;
+    c->chunk = c->options.chunk_rays >= 1024 ? (std::min<uint32_t>(c->options.chunk_rays, 1u << 28) & ~63u) : (1u << 26);
+    c->persist_blocks = 0;
 }
 
 std::vector<float> subsample_table(uint32_t spp) {  // Renderer::generate_subsample_positions, renderer.cc:135-155
@@ -258,8 +295,6 @@ std::vector<float> subsample_table(uint32_t spp) {  // Renderer::generate_subsam
     }
     return t;
 }
-
-constexpr uint32_t kWideLeaf = 2;  // largest leaf of a tree built for four-wide nodes
 
 struct FrameGeometry {
     ptd::CameraDev cam;
@@ -302,12 +337,8 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
     uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
-    // at most 32 GiB per pool (PTGPU_POOL_GIB overrides); the scheduler splits segments beyond that
-    static const uint64_t pool_gib = [] {
-        const char* v = std::getenv("PTGPU_POOL_GIB");
-        const long g = v ? std::atol(v) : 0;
-        return static_cast<uint64_t>(g >= 1 ? g : 32);
-    }();
+    // at most 32 GiB per pool (ptgpu_options.pool_gib overrides); the scheduler splits segments beyond that
+    const uint64_t pool_gib = c->options.pool_gib ? c->options.pool_gib : 32;
     const uint64_t cap_limit = (pool_gib << 30) / 48;
     cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
     // A failed allocation leaves its buffer empty (ensure frees first).  The sizes recorded in the context must never
@@ -328,8 +359,8 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     const uint32_t spill_depth = spill_depth_of(c);
     if (c->persistent && !c->persist_blocks) {
         c->persist_blocks = ptd::extend_persistent_grid(c->device, c->scene.seven_waves != 0);
-        if (const char* b = std::getenv("PTGPU_PERSIST_BLOCKS")) c->persist_blocks = static_cast<uint32_t>(std::max(1, std::atoi(b)));
-        if (std::getenv("PTGPU_VERBOSE")) std::fprintf(stderr, "[ptgpu] persistent extend grid: %u workgroups\n", c->persist_blocks);
+        if (c->options.persist_blocks) c->persist_blocks = c->options.persist_blocks;
+        if (c->options.flags & PTGPU_OPT_VERBOSE) std::fprintf(stderr, "[ptgpu] persistent extend grid: %u workgroups\n", c->persist_blocks);
     }
     const uint64_t spill_columns = c->persistent ? static_cast<uint64_t>(c->persist_blocks) * ptd::kBlock : L;
     PT_HIP(c, c->spill.ensure(static_cast<size_t>(spill_depth) * spill_columns * 4 + 16));
@@ -432,11 +463,13 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         uint64_t floor_in, floor_out;
     };
     constexpr uint64_t kMinLaunch = 1u << 16;
+#ifdef PT_DEV_DUMP_RAYS  // developer builds only (tools/sort_experiment.sh): one launch's rays written to a file
     const char* dump_path = std::getenv("PTGPU_DUMP_RAYS");
     const uint64_t dump_launch = std::getenv("PTGPU_DUMP_LAUNCH") ? std::strtoull(std::getenv("PTGPU_DUMP_LAUNCH"), nullptr, 10) : 0;
+#endif
     std::vector<Frame> frames;
     float ms = 0.0f;
-    const bool verbose_launches = std::getenv("PTGPU_VERBOSE") && std::atoi(std::getenv("PTGPU_VERBOSE")) >= 2;
+    const bool verbose_launches = (c->options.flags & PTGPU_OPT_VERBOSE_LAUNCHES) != 0;
     // Rays carry their own depth, so generations may mix: when what a generation spawned still fits a launch together
     // with the next batch's camera rays, it is not launched on its own — the camera rays go on top of it in its pool.
     // Launches stay full that way (a generation shrinks from bounce to bounce; the alpha pass-through chains at the
@@ -506,7 +539,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
                              static_cast<unsigned long long>(out.extend_launches), n, f.pool, static_cast<unsigned long long>(in.top),
                              static_cast<unsigned long long>(op.top), frames.size());
             const ptd::RayQueue rq = in.at(offset);
-            if (dump_path && out.extend_launches == dump_launch) {  // developer aid: one launch's rays as raw float4 o[n], d[n]
+#ifdef PT_DEV_DUMP_RAYS
+            if (dump_path && out.extend_launches == dump_launch) {  // one launch's rays as raw float4 o[n], d[n]
                 std::vector<float4> buf(2ull * n);
                 PT_HIP(c, hipMemcpy(buf.data(), rq.o, n * 16ull, hipMemcpyDeviceToHost));
                 PT_HIP(c, hipMemcpy(buf.data() + n, rq.d, n * 16ull, hipMemcpyDeviceToHost));
@@ -515,6 +549,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
                     std::fclose(f);
                 }
             }
+#endif
             PT_HIP(c, hipEventRecord(c->ev[0], st));
             run_extend(c, st, rq, n, hits, d_tc, c->ev[6]);
             PT_HIP(c, hipEventRecord(c->ev[1], st));
@@ -559,7 +594,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.wave_inner_iterations = tc.wave_inner;
         out.wave_triangle_iterations = tc.wave_tri;
         out.nodes_from_lds = tc.census[1][0];
-        if (std::getenv("PTGPU_VERBOSE")) {
+        if (c->options.flags & PTGPU_OPT_VERBOSE) {
             std::fprintf(stderr, "[ptgpu] node visits served from LDS: %llu of %llu; rays that touch no instance: %llu\n", tc.census[1][0], tc.nodes,
                          tc.census[1][1]);
             static const char* names[4] = {"service", "-", "inner", "leaf"};
@@ -654,11 +689,8 @@ int ptgpu_create(int device_id, ptgpu_ctx** out) {
     d.sample_step = 1;
     d.tile_step = 1;
     ctx->settings = d;
-    if (const char* m = std::getenv("PTGPU_EXTEND")) ctx->persistent = std::strcmp(m, "simple") != 0;
-    if (const char* k = std::getenv("PTGPU_CHUNK")) {
-        long v = std::atol(k);
-        if (v >= 1024) ctx->chunk = static_cast<uint32_t>(std::min<long>(v, 1l << 28)) & ~63u;
-    }
+    ctx->options = options_from_environment();
+    apply_options(ctx.get());
     *out = ctx.release();
     return PTGPU_OK;
 }
@@ -684,591 +716,31 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
     c->settings = *s;
     return PTGPU_OK;
 }
+int ptgpu_set_options(ptgpu_ctx* c, const ptgpu_options* o) {
+    if (!c || !o) return PTGPU_E_INVALID;
+    if (o->flags & ~(PTGPU_OPT_EXTEND_SIMPLE | PTGPU_OPT_REFERENCE_SPLITS | PTGPU_OPT_GREEDY_COLLAPSE | PTGPU_OPT_LINEAR_TLAS |
+                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES))
+        return c->fail(PTGPU_E_INVALID, "set_options: unknown flag bits 0x%x", o->flags);
+    if ((o->chunk_rays && (o->chunk_rays < 1024 || o->chunk_rays > (1u << 28))) || o->pool_gib > 256 ||
+        (o->traverse_waves && o->traverse_waves != 6 && o->traverse_waves != 7) || o->leaf_vote > 16 || o->build_threads > 64)
+        return c->fail(PTGPU_E_INVALID, "set_options: a value is outside its range (see ptgpu.h)");
+    c->options = *o;
+    apply_options(c);
+    return PTGPU_OK;
+}
+int ptgpu_get_options(const ptgpu_ctx* c, ptgpu_options* out) {
+    if (!c || !out) return PTGPU_E_INVALID;
+    *out = c->options;
+    return PTGPU_OK;
+}
 int ptgpu_get_render_settings(const ptgpu_ctx* c, ptgpu_settings* out) {
     if (!c || !out) return PTGPU_E_INVALID;
     *out = c->settings;
     return PTGPU_OK;
 }
 
-int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap* env) {
-    if (!c || !model) return PTGPU_E_INVALID;
-    PT_HIP(c, hipSetDevice(c->device));
-    c->scene_loaded = false;
-    // ---- validate what the kernels index with ----
-    for (uint32_t i = 0; i < model->n_meshes; ++i) {
-        const ptgpu_mesh& m = model->meshes[i];
-        if (m.n_indices % 3 != 0) return c->fail(PTGPU_E_INVALID, "mesh %u: index count %u is not a multiple of 3", i, m.n_indices);
-        if (static_cast<uint64_t>(m.first_vertex) + m.n_vertices > model->n_vertices ||
-            static_cast<uint64_t>(m.first_index) + m.n_indices > model->n_indices)
-            return c->fail(PTGPU_E_INVALID, "mesh %u: vertex/index range outside the model arrays", i);
-        if (m.material_index >= model->n_materials) return c->fail(PTGPU_E_INVALID, "mesh %u: material index out of range", i);
-        for (uint32_t k = 0; k < m.n_indices; ++k)
-            if (model->indices[m.first_index + k] >= m.n_vertices)
-                return c->fail(PTGPU_E_INVALID, "mesh %u: index %u out of range", i, k);
-    }
-    for (uint32_t i = 0; i < model->n_objects; ++i)
-        if (model->objects[i].mesh_index >= model->n_meshes) return c->fail(PTGPU_E_INVALID, "object %u: mesh index out of range", i);
-    if (model->n_objects >= (1u << 30)) return c->fail(PTGPU_E_INVALID, "too many objects");
-    for (uint32_t i = 0; i < model->n_materials; ++i) {
-        const ptgpu_material& m = model->materials[i];
-        const int32_t tex[5] = {m.base_color_texture, m.metallic_roughness_texture, m.normal_texture, m.transmission_texture,
-                                m.emissive_texture};
-        for (int32_t t : tex)
-            if (t >= static_cast<int32_t>(model->n_images)) return c->fail(PTGPU_E_INVALID, "material %u: texture index out of range", i);
-    }
-    for (uint32_t i = 0; i < model->n_images; ++i) {
-        const ptgpu_image& im = model->images[i];
-        if (im.width <= 0 || im.height <= 0 || im.texel_offset + static_cast<uint64_t>(im.width) * im.height > model->n_texels)
-            return c->fail(PTGPU_E_INVALID, "image %u: bad size or texel range", i);
-    }
-    if (model->n_texels >= (1ull << 32)) return c->fail(PTGPU_E_INVALID, "texel pool too large");
-
-    const ptgpu_settings s = c->settings;
-    const bool naive = s.accel_struct_type == PTGPU_AS_NAIVE;
-    // Four-wide nodes are for throughput, not for the reference's visiting order: their trees get small leaves (fewer
-    // triangle tests per ray, a few more node visits; measured best at 2), whatever maxTrianglesPerBVHLeaf says.
-    const bool want_wide = (s.flags & PTGPU_FLAG_WIDE_NODES) && c->persistent && !naive;
-    const uint32_t leaf_setting = s.max_triangles_per_bvh_leaf ? s.max_triangles_per_bvh_leaf : 1;
-    const uint32_t max_leaf = want_wide ? std::min(leaf_setting, kWideLeaf) : leaf_setting;
-    // ... and are collapsed from a tree of lower expected cost than the reference's (2 % fewer node visits per ray);
-    // PTGPU_WIDE_SPLITS=reference keeps the reference's splits under the wide nodes.
-    const char* splits_env = std::getenv("PTGPU_WIDE_SPLITS");
-    const bool tuned_splits = want_wide && !(splits_env && std::strcmp(splits_env, "reference") == 0);
-
-    // ---- acceleration structure (BVH_AS::BVH_AS, acceleration_structure.cc:352-390) ----
-    pth::InstanceTable table;
-    pth::build_instances(*model, table);
-    std::vector<ptd::DevNode> all_nodes;
-    std::vector<ptd::DevTri> all_tris;
-    std::vector<uint32_t> mesh_root(model->n_meshes);
-    c->bvh_info.assign(model->n_meshes, ptgpu_bvh_info{});
-    c->max_depth = 0;
-    for (uint32_t i = 0; i < model->n_meshes; ++i) {
-        const ptgpu_mesh& m = model->meshes[i];
-        pth::MeshTree tree;
-        if (s.accel_struct_type == PTGPU_AS_LBVH) {
-            std::string err;
-            if (!pth::build_mesh_tree_lbvh(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf,
-                                           c->stream, tree, &err))
-                return c->fail(PTGPU_E_HIP, "mesh %u: %s", i, err.c_str());
-        } else {
-            pth::build_mesh_tree(model->vertices + m.first_vertex, model->indices + m.first_index, m.n_indices, max_leaf, naive,
-                                 tuned_splits, tree);
-        }
-        if (all_tris.size() + tree.tris.size() >= (1ull << 31) - 2 || all_nodes.size() + tree.nodes.size() >= (1ull << 31))
-            return c->fail(PTGPU_E_INVALID, "scene exceeds 2^31 triangles or nodes");
-        pth::relocate(tree, static_cast<uint32_t>(all_nodes.size()), static_cast<uint32_t>(all_tris.size()));
-        mesh_root[i] = tree.root;
-        c->bvh_info[i] = tree.info;
-        c->max_depth = std::max(c->max_depth, tree.info.max_depth);
-        all_nodes.insert(all_nodes.end(), tree.nodes.begin(), tree.nodes.end());
-        all_tris.insert(all_tris.end(), tree.tris.begin(), tree.tris.end());
-    }
-    for (ptd::DevXform& xf : table.xforms) {
-        xf.root = mesh_root[xf.mesh_index];
-        const ptgpu_material& mat = model->materials[model->meshes[xf.mesh_index].material_index];
-        const bool double_sided = mat.double_sided || mat.has_volume;  // :377-378
-        xf.cull = double_sided ? 0u : 1u;
-    }
-    std::memcpy(c->scene_min, table.scene_min, 12);
-    std::memcpy(c->scene_max, table.scene_max, 12);
-
-    // The most visited nodes go first in the node array: the traversal kernel keeps nodes[0 .. n_top) in LDS, which
-    // takes their fetches off the vector L1's address unit (the busiest unit of that kernel).  "Most visited" is
-    // estimated the way the surface area heuristic does: a node is visited in proportion to the area of its box,
-    // summed over the instances of its mesh (scaled by the instance's size).  Only the numbering changes.
-    uint32_t n_top = 0;
-    std::vector<float> mesh_weight(model->n_meshes, 0.0f);  // summed squared scale of a mesh's instances
-    for (const ptd::DevXform& xf : table.xforms) {
-        const float* m = xf.model;  // columns c0 c1 c2 (c3 = translation)
-        const float det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[3] * (m[1] * m[8] - m[2] * m[7]) + m[6] * (m[1] * m[5] - m[2] * m[4]);
-        const float scale = std::cbrt(std::fabs(det));
-        mesh_weight[xf.mesh_index] += scale * scale;
-    }
-    if (!all_nodes.empty()) {
-        auto half_area = [](const float* lo, const float* hi) {
-            const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-            return dx * dy + dx * dz + dy * dz;
-        };
-        struct Entry {
-            float priority;
-            uint32_t node, mesh;
-            bool operator<(const Entry& o) const { return priority < o.priority; }
-        };
-        std::priority_queue<Entry> queue;
-        for (uint32_t i = 0; i < model->n_meshes; ++i)
-            if (!(mesh_root[i] & PT_LEAF_BIT) && mesh_weight[i] > 0.0f) queue.push({std::numeric_limits<float>::max(), mesh_root[i], i});
-        std::vector<uint32_t> order;  // old indices of the chosen nodes
-        while (!queue.empty() && order.size() < static_cast<size_t>(ptd::kTopNodes)) {
-            const Entry e = queue.top();
-            queue.pop();
-            order.push_back(e.node);
-            const ptd::DevNode& nd = all_nodes[e.node];
-            if (!(nd.left & PT_LEAF_BIT)) queue.push({half_area(nd.l_lo, nd.l_hi) * mesh_weight[e.mesh], nd.left, e.mesh});
-            if (!(nd.right & PT_LEAF_BIT)) queue.push({half_area(nd.r_lo, nd.r_hi) * mesh_weight[e.mesh], nd.right, e.mesh});
-        }
-        n_top = static_cast<uint32_t>(order.size());
-        std::vector<uint32_t> new_index(all_nodes.size(), PT_NO_NODE);
-        for (uint32_t k = 0; k < n_top; ++k) new_index[order[k]] = k;
-        uint32_t next = n_top;
-        for (uint32_t i = 0; i < all_nodes.size(); ++i)
-            if (new_index[i] == PT_NO_NODE) new_index[i] = next++;
-        std::vector<ptd::DevNode> moved(all_nodes.size());
-        for (uint32_t i = 0; i < all_nodes.size(); ++i) {
-            ptd::DevNode n = all_nodes[i];
-            if (!(n.left & PT_LEAF_BIT)) n.left = new_index[n.left];
-            if (!(n.right & PT_LEAF_BIT)) n.right = new_index[n.right];
-            moved[new_index[i]] = n;
-        }
-        all_nodes.swap(moved);
-        for (ptd::DevXform& xf : table.xforms)
-            if (!(xf.root & PT_LEAF_BIT)) xf.root = new_index[xf.root];
-    }
-
-    // ---- a tree over the instances' boxes when there are many of them (the instance pass then culls before it tests) ----
-    // Balanced by count (median split along the widest axis of the box centres), so its depth is ceil(log2(n)).
-    std::vector<ptd::TlasNode> tlas;
-    const char* tlas_env = std::getenv("PTGPU_TLAS");  // "linear": every ray tests every bound whatever their number (cross-check)
-    if (table.instances.size() > ptd::kTlasLinearMax && !(tlas_env && !std::strcmp(tlas_env, "linear"))) {
-        std::vector<uint32_t> order(table.instances.size());
-        for (uint32_t k = 0; k < order.size(); ++k) order[k] = k;
-        // depth-first emission with an explicit work list: a range becomes a node, then its left half, then its right half;
-        // `skip` = the index after the node's subtree = node + 2 * count - 1
-        struct Range {
-            uint32_t begin, end;
-        };
-        std::vector<Range> todo{{0u, static_cast<uint32_t>(order.size())}};
-        while (!todo.empty()) {
-            const Range r = todo.back();
-            todo.pop_back();
-            const uint32_t count = r.end - r.begin;
-            ptd::TlasNode nd;
-            float clo[3], chi[3];
-            for (int a = 0; a < 3; ++a) {
-                nd.lo[a] = clo[a] = std::numeric_limits<float>::max();
-                nd.hi[a] = chi[a] = std::numeric_limits<float>::lowest();
-            }
-            for (uint32_t i = r.begin; i < r.end; ++i) {
-                const float* d = table.instances[order[i]].dop;
-                for (int a = 0; a < 3; ++a) {
-                    nd.lo[a] = std::min(nd.lo[a], d[2 * a]);
-                    nd.hi[a] = std::max(nd.hi[a], d[2 * a + 1]);
-                    const float c = d[2 * a] + d[2 * a + 1];
-                    clo[a] = std::min(clo[a], c);
-                    chi[a] = std::max(chi[a], c);
-                }
-            }
-            nd.skip = static_cast<uint32_t>(tlas.size()) + 2u * count - 1u;
-            nd.inst = (count == 1) ? order[r.begin] : PT_NO_NODE;
-            tlas.push_back(nd);
-            if (count == 1) continue;
-            int axis = 0;
-            for (int a = 1; a < 3; ++a)
-                if (chi[a] - clo[a] > chi[axis] - clo[axis]) axis = a;
-            const uint32_t mid = r.begin + count / 2;
-            std::nth_element(order.begin() + r.begin, order.begin() + mid, order.begin() + r.end, [&](uint32_t x, uint32_t y) {
-                const float* dx = table.instances[x].dop;
-                const float* dy = table.instances[y].dop;
-                const float cx = dx[2 * axis] + dx[2 * axis + 1], cy = dy[2 * axis] + dy[2 * axis + 1];
-                return cx < cy || (cx == cy && x < y);
-            });
-            todo.push_back({mid, r.end});    // popped after the whole left half
-            todo.push_back({r.begin, mid});
-        }
-    }
-
-    // ---- optional four-wide nodes (PTGPU_FLAG_WIDE_NODES): inner children pulled up into their parent, largest box first ----
-    std::vector<ptd::Node4> wide;
-    uint32_t n_top4 = 0;
-    bool seven_waves = false;
-    if (want_wide && !all_nodes.empty()) {
-        struct Child {
-            uint32_t ref;
-            float lo[3], hi[3];
-        };
-        auto half_area = [](const Child& ch) {
-            const float dx = ch.hi[0] - ch.lo[0], dy = ch.hi[1] - ch.lo[1], dz = ch.hi[2] - ch.lo[2];
-            return dx * dy + dx * dz + dy * dz;
-        };
-        auto children_of = [&](uint32_t node, Child out[2]) {
-            const ptd::DevNode& nd = all_nodes[node];
-            out[0].ref = nd.left;
-            out[1].ref = nd.right;
-            std::memcpy(out[0].lo, nd.l_lo, 12); std::memcpy(out[0].hi, nd.l_hi, 12);
-            std::memcpy(out[1].lo, nd.r_lo, 12); std::memcpy(out[1].hi, nd.r_hi, 12);
-        };
-        std::vector<uint32_t> depth_of;                               // per wide node
-        uint32_t max_depth4 = 0;
-        struct Todo {
-            uint32_t binary, wide_index;
-        };
-        std::vector<Todo> todo;
-        auto make = [&](uint32_t binary, uint32_t depth) -> uint32_t {
-            const uint32_t w = static_cast<uint32_t>(wide.size());
-            wide.emplace_back();
-            depth_of.push_back(depth);
-            max_depth4 = std::max(max_depth4, depth);
-            todo.push_back({binary, w});
-            return w;
-        };
-        std::vector<uint32_t> mesh_root4(model->n_meshes, PT_NO_NODE);
-        std::vector<uint32_t> binary_root(model->n_meshes, PT_NO_NODE);
-        for (const ptd::DevXform& xf : table.xforms) binary_root[xf.mesh_index] = xf.root;
-        // Which binary nodes survive as four-wide nodes.  A ray pays one visit per surviving node whose box it enters, so
-        // the expected number of visits is the summed surface area of the surviving nodes; that sum is minimised exactly by
-        // dynamic programming over the binary tree (Ylitie, Karras, Laine: Efficient incoherent ray traversal on GPUs
-        // through compressed wide BVHs, 2017, section 4.1): cost[n][k] = least area below n when n's subtree is
-        // represented by at most k+1 roots (k = 0: n itself is a wide node), part[n][k] = how many of them its left child gets
-        // (0 = the solution for one root fewer is as good).  PTGPU_WIDE_COLLAPSE=greedy selects the older rule instead
-        // (always pull up the child with the largest box).
-        const char* collapse_env = std::getenv("PTGPU_WIDE_COLLAPSE");
-        const bool optimal_collapse = !(collapse_env && !std::strcmp(collapse_env, "greedy"));
-        std::vector<float> cost;
-        std::vector<uint8_t> part;
-        auto cost_of = [&](uint32_t ref, int roots) { return (ref & PT_LEAF_BIT) ? 0.0f : cost[static_cast<size_t>(ref) * 4 + (roots - 1)]; };
-        if (optimal_collapse) {
-            cost.assign(all_nodes.size() * 4, 0.0f);
-            part.assign(all_nodes.size() * 4, 0);
-            std::vector<uint32_t> order;  // every node after its children: reverse of a pre-order walk
-            for (uint32_t m = 0; m < model->n_meshes; ++m) {
-                if (binary_root[m] == PT_NO_NODE || (binary_root[m] & PT_LEAF_BIT)) continue;
-                const size_t first = order.size();
-                order.push_back(binary_root[m]);
-                for (size_t i = first; i < order.size(); ++i) {
-                    const ptd::DevNode& nd = all_nodes[order[i]];
-                    if (!(nd.left & PT_LEAF_BIT)) order.push_back(nd.left);
-                    if (!(nd.right & PT_LEAF_BIT)) order.push_back(nd.right);
-                }
-            }
-            for (size_t i = order.size(); i-- > 0;) {
-                const uint32_t n = order[i];
-                const ptd::DevNode& nd = all_nodes[n];
-                float lo[3], hi[3];
-                for (int a = 0; a < 3; ++a) {
-                    lo[a] = std::min(nd.l_lo[a], nd.r_lo[a]);
-                    hi[a] = std::max(nd.l_hi[a], nd.r_hi[a]);
-                }
-                const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
-                const float own = dx * dy + dx * dz + dy * dz;
-                float below[5] = {0, 0, 0, 0, 0};  // below[k]: children represented by at most k roots, k = 2..4
-                uint8_t left_share[5] = {0, 0, 0, 0, 0};
-                for (int k = 2; k <= 4; ++k) {
-                    below[k] = std::numeric_limits<float>::infinity();
-                    for (int l = 1; l < k; ++l) {
-                        const float c = cost_of(nd.left, l) + cost_of(nd.right, k - l);
-                        if (c < below[k]) {
-                            below[k] = c;
-                            left_share[k] = static_cast<uint8_t>(l);
-                        }
-                    }
-                }
-                float* c = &cost[static_cast<size_t>(n) * 4];
-                uint8_t* p4 = &part[static_cast<size_t>(n) * 4];
-                c[0] = own + below[4];       // one root: n is a wide node, its (at most four) children come from below[4]
-                p4[0] = left_share[4];
-                for (int k = 2; k <= 4; ++k) {  // k roots: n dissolves into its children's roots, unless k - 1 roots do as well
-                    if (c[k - 2] <= below[k]) {
-                        c[k - 1] = c[k - 2];
-                        p4[k - 1] = 0;
-                    } else {
-                        c[k - 1] = below[k];
-                        p4[k - 1] = left_share[k];
-                    }
-                }
-            }
-        }
-        for (uint32_t m = 0; m < model->n_meshes; ++m) {
-            const uint32_t root = binary_root[m];
-            if (root == PT_NO_NODE) continue;  // mesh without an instance
-            if (root & PT_LEAF_BIT) {
-                mesh_root4[m] = root;
-                continue;
-            }
-            mesh_root4[m] = make(root, 1);
-            while (!todo.empty()) {
-                const Todo t = todo.back();
-                todo.pop_back();
-                Child ch[4];
-                int n_ch = 2;
-                children_of(t.binary, ch);
-                if (optimal_collapse) {
-                    // follow the recorded decisions: `roots` of the subtree below a child become children of this wide node
-                    n_ch = 0;
-                    struct Open {
-                        Child c;
-                        int roots;
-                    };
-                    Open open[8];
-                    int n_open = 0;
-                    Child two[2];
-                    children_of(t.binary, two);
-                    const int l = part[static_cast<size_t>(t.binary) * 4];
-                    open[n_open++] = {two[1], 4 - l};
-                    open[n_open++] = {two[0], l};
-                    while (n_open) {
-                        const Open o = open[--n_open];
-                        if ((o.c.ref & PT_LEAF_BIT) || o.roots == 1) {
-                            ch[n_ch++] = o.c;
-                            continue;
-                        }
-                        const int share = part[static_cast<size_t>(o.c.ref) * 4 + (o.roots - 1)];
-                        if (share == 0) {
-                            open[n_open++] = {o.c, o.roots - 1};
-                            continue;
-                        }
-                        children_of(o.c.ref, two);
-                        open[n_open++] = {two[1], o.roots - share};
-                        open[n_open++] = {two[0], share};
-                    }
-                }
-                while (!optimal_collapse && n_ch < 4) {  // pull up the inner child with the largest box
-                    int best = -1;
-                    float best_area = -1.0f;
-                    for (int k = 0; k < n_ch; ++k)
-                        if (!(ch[k].ref & PT_LEAF_BIT) && half_area(ch[k]) > best_area) {
-                            best_area = half_area(ch[k]);
-                            best = k;
-                        }
-                    if (best < 0) break;
-                    Child two[2];
-                    children_of(ch[best].ref, two);
-                    ch[best] = two[0];
-                    ch[n_ch++] = two[1];
-                }
-                ptd::Node4 nd;
-                std::memset(&nd, 0, sizeof(nd));
-                // the node's own box, and per axis the step that reaches its far side in 255 steps (plane = origin + step * q,
-                // evaluated in binary32 as the kernel's slow path does; low planes round down, high planes up)
-                for (int a = 0; a < 3; ++a) {
-                    float lo = ch[0].lo[a], hi = ch[0].hi[a];
-                    for (int k = 1; k < n_ch; ++k) {
-                        lo = std::min(lo, ch[k].lo[a]);
-                        hi = std::max(hi, ch[k].hi[a]);
-                    }
-                    float step = (hi - lo) / 255.0f;
-                    if (!(step > 0.0f) || !(step < std::numeric_limits<float>::max())) step = 0.0f;
-                    // (far from the origin one unit in the last place of `hi` is many of `step`: grow geometrically)
-                    for (float grow = 1.0f / 1024.0f; step > 0.0f && lo + step * 255.0f < hi; grow *= 2.0f)
-                        step = std::max(std::nextafter(step, std::numeric_limits<float>::max()), step * (1.0f + grow));
-                    nd.origin[a] = lo;
-                    nd.scale[a] = step;
-                    for (int k = 0; k < n_ch; ++k) {
-                        int ql = 0, qh = 0;
-                        if (step > 0.0f) {
-                            ql = std::clamp(static_cast<int>(std::floor((ch[k].lo[a] - lo) / step)), 0, 255);
-                            while (ql > 0 && lo + step * static_cast<float>(ql) > ch[k].lo[a]) --ql;
-                            qh = std::clamp(static_cast<int>(std::ceil((ch[k].hi[a] - lo) / step)), 0, 255);
-                            while (qh < 255 && lo + step * static_cast<float>(qh) < ch[k].hi[a]) ++qh;
-                        }
-                        nd.qlo[a] |= static_cast<uint32_t>(ql) << (8 * k);
-                        nd.qhi[a] |= static_cast<uint32_t>(qh) << (8 * k);
-                    }
-                }
-                // An unused slot is not marked "absent": it names the padding record after the last triangle (one degenerate
-                // triangle, never hit) as a leaf, inside an inverted box (low planes 255, high planes 0) that no ray enters —
-                // except in a node of zero extent, where the degenerate triangle is tested and missed.  The kernel so needs no
-                // test for a slot's existence.
-                const uint32_t dummy_leaf = PT_LEAF_BIT | static_cast<uint32_t>(all_tris.size());
-                for (int k = n_ch; k < 4; ++k)
-                    for (int a = 0; a < 3; ++a) {
-                        nd.qlo[a] |= 255u << (8 * k);
-                        nd.qhi[a] &= ~(255u << (8 * k));
-                    }
-                for (int k = 0; k < 4; ++k)
-                    nd.ref[k] = (k >= n_ch) ? dummy_leaf
-                                            : ((ch[k].ref & PT_LEAF_BIT) ? ch[k].ref : make(ch[k].ref, depth_of[t.wide_index] + 1));
-                wide[t.wide_index] = nd;
-            }
-        }
-        for (ptd::DevXform& xf : table.xforms) xf.root4 = mesh_root4[xf.mesh_index];
-        // Which form of the four-wide kernel: seven workgroups per CU when nodes and triangles fit the Infinity Cache with room
-        // to spare (the kernel is then limited by the latency of a step), six otherwise (limited by the gather path: more
-        // wavefronts only add to it).  PTGPU_TRAVERSE_WAVES=6 / 7 overrides.
-        {
-            const uint64_t geometry_bytes = static_cast<uint64_t>(wide.size()) * sizeof(ptd::Node4) + (all_tris.size() + 2) * sizeof(ptd::TriQ);
-            seven_waves = geometry_bytes <= (128ull << 20);
-            if (const char* e = std::getenv("PTGPU_TRAVERSE_WAVES")) seven_waves = std::atoi(e) == 7;
-        }
-        const size_t top_capacity4 = seven_waves ? ptd::top_nodes7_for(static_cast<uint32_t>(table.instances.size())) : ptd::kTopNodes4;
-        // the most visited wide nodes first (same estimate as for the binary nodes), kept in LDS by the kernel
-        {
-            struct Entry {
-                float priority;
-                uint32_t node, mesh;
-                bool operator<(const Entry& o) const { return priority < o.priority; }
-            };
-            std::priority_queue<Entry> queue;
-            for (uint32_t m = 0; m < model->n_meshes; ++m)
-                if (mesh_root4[m] != PT_NO_NODE && !(mesh_root4[m] & PT_LEAF_BIT) && mesh_weight[m] > 0.0f)
-                    queue.push({std::numeric_limits<float>::max(), mesh_root4[m], m});
-            std::vector<uint32_t> order;
-            while (!queue.empty() && order.size() < top_capacity4) {
-                const Entry e = queue.top();
-                queue.pop();
-                order.push_back(e.node);
-                const ptd::Node4& nd = wide[e.node];
-                for (int k = 0; k < 4; ++k)
-                    if (nd.ref[k] != PT_NO_NODE && !(nd.ref[k] & PT_LEAF_BIT)) {
-                        float ext[3];
-                        for (int a = 0; a < 3; ++a)
-                            ext[a] = nd.scale[a] * static_cast<float>(static_cast<int>((nd.qhi[a] >> (8 * k)) & 0xffu) -
-                                                                      static_cast<int>((nd.qlo[a] >> (8 * k)) & 0xffu));
-                        queue.push({(ext[0] * ext[1] + ext[0] * ext[2] + ext[1] * ext[2]) * mesh_weight[e.mesh], nd.ref[k], e.mesh});
-                    }
-            }
-            n_top4 = static_cast<uint32_t>(order.size());
-            std::vector<uint32_t> new_index(wide.size(), PT_NO_NODE);
-            for (uint32_t k = 0; k < n_top4; ++k) new_index[order[k]] = k;
-            uint32_t next = n_top4;
-            for (uint32_t i = 0; i < wide.size(); ++i)
-                if (new_index[i] == PT_NO_NODE) new_index[i] = next++;
-            std::vector<ptd::Node4> moved(wide.size());
-            for (uint32_t i = 0; i < wide.size(); ++i) {
-                ptd::Node4 n = wide[i];
-                for (int k = 0; k < 4; ++k)
-                    if (n.ref[k] != PT_NO_NODE && !(n.ref[k] & PT_LEAF_BIT)) n.ref[k] = new_index[n.ref[k]];
-                moved[new_index[i]] = n;
-            }
-            wide.swap(moved);
-            for (ptd::DevXform& xf : table.xforms)
-                if (xf.root4 != PT_NO_NODE && !(xf.root4 & PT_LEAF_BIT)) xf.root4 = new_index[xf.root4];
-        }
-        // a visit pushes up to three children: the stack can hold 3 entries per level
-        c->max_depth = std::max(c->max_depth, 3u * max_depth4 + 1u);
-        if (std::getenv("PTGPU_VERBOSE"))
-            std::fprintf(stderr, "[ptgpu] four-wide nodes: %zu (from %zu binary), depth %u, kernel form: %d workgroups per CU\n", wide.size(),
-                         all_nodes.size(), max_depth4, seven_waves ? 7 : 6);
-    }
-
-    // ---- shading data ----
-    // corners: every triangle's three vertices de-indexed, in mesh order (the hit record's triangle index / 3)
-    std::vector<uint64_t> mesh_tri_base(model->n_meshes);
-    uint64_t n_shade_tris = 0;
-    for (uint32_t i = 0; i < model->n_meshes; ++i) {
-        mesh_tri_base[i] = n_shade_tris;
-        n_shade_tris += model->meshes[i].n_indices / 3;
-    }
-    if (n_shade_tris >= (1ull << 32)) return c->fail(PTGPU_E_INVALID, "scene exceeds 2^32 triangles");
-    std::vector<ptgpu_vertex> corners(static_cast<size_t>(n_shade_tris) * 3);
-    for (uint32_t i = 0; i < model->n_meshes; ++i) {
-        const ptgpu_mesh& m = model->meshes[i];
-        ptgpu_vertex* dst = corners.data() + mesh_tri_base[i] * 3;
-        const uint32_t n_corner = m.n_indices - m.n_indices % 3;
-        for (uint32_t k = 0; k < n_corner; ++k) {
-            const uint32_t v = model->indices[m.first_index + k];
-            if (v >= m.n_vertices) return c->fail(PTGPU_E_INVALID, "mesh %u: index %u beyond its %u vertices", i, v, m.n_vertices);
-            dst[k] = model->vertices[m.first_vertex + v];
-        }
-    }
-    auto texture_of = [&](int32_t image, ptd::DevTexture& out) -> bool {
-        out = ptd::DevTexture{0, 0, 0u};
-        if (image < 0) return true;
-        if (static_cast<uint32_t>(image) >= model->n_images) return false;
-        const ptgpu_image& im = model->images[image];
-        if (im.width <= 0 || im.height <= 0 || im.texel_offset + static_cast<uint64_t>(im.width) * im.height > model->n_texels ||
-            im.texel_offset >= (1ull << 32))
-            return false;
-        out = ptd::DevTexture{im.width, im.height, static_cast<uint32_t>(im.texel_offset)};
-        return true;
-    };
-    std::vector<ptd::DevObject> objects(model->n_objects);
-    c->object_mesh.resize(model->n_objects);
-    for (uint32_t i = 0; i < model->n_objects; ++i) {
-        const ptgpu_object& o = model->objects[i];
-        ptd::DevObject& d = objects[i];
-        std::memset(&d, 0, sizeof(d));
-        for (int col = 0; col < 4; ++col)
-            for (int r = 0; r < 3; ++r) {
-                d.model[col * 3 + r] = o.model_matrix[col * 4 + r];
-                d.normal[col * 3 + r] = o.normal_matrix[col * 4 + r];
-            }
-        d.tri_base = static_cast<uint32_t>(mesh_tri_base[o.mesh_index]);
-        c->object_mesh[i] = o.mesh_index;
-        const ptgpu_material& m = model->materials[model->meshes[o.mesh_index].material_index];
-        ptd::DevMaterial& dm = d.mat;
-        std::memcpy(dm.base_color, m.base_color_factor, 16);
-        std::memcpy(dm.emissive, m.emissive_factor, 12);
-        dm.emissive_strength = m.emissive_strength;
-        std::memcpy(dm.attenuation, m.attenuation_factor, 12);
-        dm.metallic = m.metallic_factor;
-        dm.roughness = m.roughness_factor;
-        dm.ior = m.ior;
-        dm.f0 = m.dielectric_f0;
-        dm.transmission = m.transmission_factor;
-        dm.alpha_cutoff = m.alpha_cutoff;
-        dm.double_sided = m.double_sided != 0;
-        dm.has_volume = m.has_volume != 0;
-        dm.alpha_blending = m.alpha_blending != 0;
-        if (!texture_of(m.base_color_texture, dm.base_color_tex) || !texture_of(m.metallic_roughness_texture, dm.mr_tex) ||
-            !texture_of(m.normal_texture, dm.normal_tex) || !texture_of(m.transmission_texture, dm.transmission_tex) ||
-            !texture_of(m.emissive_texture, dm.emissive_tex))
-            return c->fail(PTGPU_E_INVALID, "object %u: its material names an image that does not exist or lies outside the texel array", i);
-    }
-    static_assert(sizeof(ptgpu_vertex) == 48, "vertex is three float4");
-    static_assert(sizeof(ptd::DevObject) == 256, "object record is 256 bytes");
-    float lut[256];
-    for (int i = 0; i < 256; ++i) lut[i] = srgb_to_linear_host(static_cast<float>(i) / 255.0f);
-    const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // CPUTexture<hdr_pixel>::create_white_texture, cpu_framebuffer.cc:104
-    const float* env_px = white;
-    int env_w = 1, env_h = 1;
-    if (env && env->rgba) {
-        if (env->width <= 0 || env->height <= 0) return c->fail(PTGPU_E_INVALID, "environment map has a bad size");
-        env_px = env->rgba;
-        env_w = env->width;
-        env_h = env->height;
-    }
-
-    // traversal forms: planes grouped per axis, triangle edges precomputed (binary32 subtraction, as the test does)
-    std::vector<ptd::NodeQ> q_nodes(all_nodes.size());
-    for (size_t i = 0; i < all_nodes.size(); ++i) {
-        const ptd::DevNode& n = all_nodes[i];
-        ptd::NodeQ& q = q_nodes[i];
-        float* axes[3] = {q.x, q.y, q.z};
-        for (int a = 0; a < 3; ++a) {
-            axes[a][0] = n.l_lo[a];
-            axes[a][1] = n.r_lo[a];
-            axes[a][2] = n.l_hi[a];
-            axes[a][3] = n.r_hi[a];
-        }
-        q.left = n.left;
-        q.right = n.right;
-        q.pad0 = q.pad1 = 0;
-    }
-    // + two records of padding: the four-wide kernel reads triangles in pairs, and the first padding record is itself a leaf
-    // (one degenerate triangle: the filler of unused child slots)
-    std::vector<ptd::TriQ> q_tris(all_tris.size() + 2);
-    for (size_t k = all_tris.size(); k < q_tris.size(); ++k) {
-        std::memset(&q_tris[k], 0, sizeof(ptd::TriQ));
-        q_tris[k].leaf_count = 1;
-    }
-    uint32_t in_leaf = 0;  // the builder marks a leaf's first triangle with the leaf size; every triangle gets the rest count
-    for (size_t i = 0; i < all_tris.size(); ++i) {
-        const ptd::DevTri& t = all_tris[i];
-        ptd::TriQ& q = q_tris[i];
-        for (int a = 0; a < 3; ++a) {
-            q.p1[a] = t.p1[a];
-            q.e1[a] = t.p2[a] - t.p1[a];
-            q.e2[a] = t.p3[a] - t.p1[a];
-        }
-        q.index = t.index;
-        if (t.leaf_count) in_leaf = t.leaf_count;
-        q.leaf_count = in_leaf ? in_leaf-- : 1u;
-        q.pad = 0;
-    }
-    int rc;
-    if ((rc = upload(c, c->nodes, q_nodes.data(), q_nodes.size()))) return rc;
-    if ((rc = upload(c, c->tris, q_tris.data(), q_tris.size()))) return rc;
-    if (!wide.empty() && (rc = upload(c, c->nodes4, wide.data(), wide.size()))) return rc;
-    if (!tlas.empty() && (rc = upload(c, c->tlas, tlas.data(), tlas.size()))) return rc;
-    if ((rc = upload(c, c->instances, table.instances.data(), table.instances.size()))) return rc;
-    if ((rc = upload(c, c->xforms, table.xforms.data(), table.xforms.size()))) return rc;
-    if ((rc = upload(c, c->objects, objects.data(), objects.size()))) return rc;
-    if ((rc = upload(c, c->corners, corners.data(), corners.size()))) return rc;
-    if ((rc = upload(c, c->texels, reinterpret_cast<const uint32_t*>(model->texels), static_cast<size_t>(model->n_texels)))) return rc;
-    if ((rc = upload(c, c->env, env_px, static_cast<size_t>(env_w) * env_h * 4))) return rc;
-    if ((rc = upload(c, c->lut, lut, 256))) return rc;
-    if ((rc = upload(c, c->d_object_mesh, c->object_mesh.data(), c->object_mesh.size()))) return rc;
-
+// SceneDev's pointers = this context's scene buffers (absent optional arrays: null).
+static void point_scene_at_buffers(ptgpu_ctx* c) {
     ptd::SceneDev& sc = c->scene;
     sc.nodes = c->nodes.as<ptd::NodeQ>();
     sc.tris = c->tris.as<ptd::TriQ>();
@@ -1279,31 +751,137 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     sc.texels = c->texels.as<uint32_t>();
     sc.env = c->env.as<float4>();
     sc.srgb_lut = c->lut.as<float>();
-    sc.n_instances = static_cast<uint32_t>(table.instances.size());
-    sc.n_top_nodes = n_top;
-    sc.nodes4 = wide.empty() ? nullptr : c->nodes4.as<ptd::Node4>();
-    sc.tlas = tlas.empty() ? nullptr : c->tlas.as<ptd::TlasNode>();
-    sc.n_tlas = static_cast<uint32_t>(tlas.size());
-    sc.n_top_nodes4 = n_top4;
-    sc.seven_waves = seven_waves ? 1u : 0u;
-    {   // deep closest-hit traversals (large scenes, every program but ambient occlusion with its any-hit rays) give leaves the
-        // heavier vote in the traversal kernel's choice of phase; PTGPU_LEAF_VOTE=<1..16> overrides
-        uint64_t instanced = 0;
-        for (uint32_t i = 0; i < model->n_objects; ++i) instanced += model->meshes[model->objects[i].mesh_index].n_indices / 3;
-        sc.leaf_vote = (s.program_mode != PTGPU_PROGRAM_AO && instanced >= 500000) ? 4u : 1u;
-        if (const char* v = std::getenv("PTGPU_LEAF_VOTE")) {
-            const long k = std::atol(v);
-            if (k >= 1 && k <= 16) sc.leaf_vote = static_cast<uint32_t>(k);
-        }
+    sc.nodes4 = c->has_nodes4 ? c->nodes4.as<ptd::Node4>() : nullptr;
+    sc.tlas = sc.n_tlas ? c->tlas.as<ptd::TlasNode>() : nullptr;
+}
+
+// Device copies of a built scene and the SceneDev that points at them.
+static int upload_built_scene(ptgpu_ctx* c, const pth::BuiltScene& b, const ptgpu_model* model, const ptgpu_envmap* env) {
+    const float white[4] = {1.0f, 1.0f, 1.0f, 1.0f};  // CPUTexture<hdr_pixel>::create_white_texture, cpu_framebuffer.cc:104
+    const float* env_px = white;
+    int env_w = 1, env_h = 1;
+    if (env && env->rgba) {
+        if (env->width <= 0 || env->height <= 0) return c->fail(PTGPU_E_INVALID, "environment map has a bad size");
+        env_px = env->rgba;
+        env_w = env->width;
+        env_h = env->height;
     }
-    c->persist_blocks = 0;  // the resident grid depends on the kernel form: sized again at the next render
+    int rc;
+    if ((rc = upload(c, c->nodes, b.nodes.data(), b.nodes.size()))) return rc;
+    if ((rc = upload(c, c->tris, b.tris.data(), b.tris.size()))) return rc;
+    if (!b.nodes4.empty() && (rc = upload(c, c->nodes4, b.nodes4.data(), b.nodes4.size()))) return rc;
+    if (!b.tlas.empty() && (rc = upload(c, c->tlas, b.tlas.data(), b.tlas.size()))) return rc;
+    if ((rc = upload(c, c->instances, b.instances.data(), b.instances.size()))) return rc;
+    if ((rc = upload(c, c->xforms, b.xforms.data(), b.xforms.size()))) return rc;
+    if ((rc = upload(c, c->objects, b.objects.data(), b.objects.size()))) return rc;
+    if ((rc = upload(c, c->corners, b.corners.data(), b.corners.size()))) return rc;
+    if ((rc = upload(c, c->texels, reinterpret_cast<const uint32_t*>(model->texels), static_cast<size_t>(model->n_texels)))) return rc;
+    if ((rc = upload(c, c->env, env_px, static_cast<size_t>(env_w) * env_h * 4))) return rc;
+    if ((rc = upload(c, c->lut, b.srgb_lut, 256))) return rc;
+    if ((rc = upload(c, c->d_object_mesh, b.object_mesh.data(), b.object_mesh.size()))) return rc;
+
+    ptd::SceneDev& sc = c->scene;
+    sc.n_instances = static_cast<uint32_t>(b.instances.size());
+    sc.n_top_nodes = b.n_top;
+    sc.n_tlas = static_cast<uint32_t>(b.tlas.size());
+    sc.n_top_nodes4 = b.n_top4;
+    sc.seven_waves = b.seven_waves ? 1u : 0u;
+    sc.leaf_vote = b.leaf_vote;
     sc.env_w = env_w;
     sc.env_h = env_h;
-    sc.env_rot = s.envmap_rotation;
+    c->has_nodes4 = !b.nodes4.empty();
+    point_scene_at_buffers(c);
+    c->bvh_info = b.bvh_info;
+    c->object_mesh = b.object_mesh;
+    c->max_depth = b.max_depth;
+    std::memcpy(c->scene_min, b.scene_min, 12);
+    std::memcpy(c->scene_max, b.scene_max, 12);
+    return PTGPU_OK;
+}
+
+int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap* env) {
+    if (!c || !model) return PTGPU_E_INVALID;
+    PT_HIP(c, hipSetDevice(c->device));
+    c->scene_loaded = false;
+    std::string err;
+    if (!pth::validate_model(*model, &err)) return c->fail(PTGPU_E_INVALID, "%s", err.c_str());  // what the kernels index with
+    const ptgpu_settings s = c->settings;
+    pth::BuildOptions bo;
+    bo.max_leaf = s.max_triangles_per_bvh_leaf;
+    bo.naive = s.accel_struct_type == PTGPU_AS_NAIVE;
+    bo.want_wide = (s.flags & PTGPU_FLAG_WIDE_NODES) && c->persistent;
+    bo.reference_splits = (c->options.flags & PTGPU_OPT_REFERENCE_SPLITS) != 0;
+    bo.greedy_collapse = (c->options.flags & PTGPU_OPT_GREEDY_COLLAPSE) != 0;
+    bo.linear_tlas = (c->options.flags & PTGPU_OPT_LINEAR_TLAS) != 0;
+    bo.traverse_waves = c->options.traverse_waves;
+    bo.leaf_vote = c->options.leaf_vote;
+    bo.build_threads = c->options.build_threads;
+    bo.program_mode = s.program_mode;
+    bo.verbose = (c->options.flags & PTGPU_OPT_VERBOSE) != 0;
+    if (s.accel_struct_type == PTGPU_AS_LBVH) {
+        hipStream_t st = c->stream;
+        bo.mesh_builder = [st](const ptgpu_vertex* v, const uint32_t* idx, uint32_t n_idx, uint32_t max_leaf, pth::MeshTree& tree, std::string* e) {
+            return pth::build_mesh_tree_lbvh(v, idx, n_idx, max_leaf, st, tree, e);
+        };
+    }
+    pth::BuiltScene built;
+    int code = PTGPU_E_INVALID;
+    if (!pth::build_scene(*model, bo, built, &err, &code)) return c->fail(code, "%s", err.c_str());
+    const int rc = upload_built_scene(c, built, model, env);
+    if (rc) return rc;
+    c->scene.env_rot = s.envmap_rotation;
+    c->persist_blocks = 0;  // the resident grid depends on the kernel form: sized again at the next render
     c->scene_settings = s;
     c->scene_loaded = true;
     return PTGPU_OK;
 }
+
+int ptgpu_load_scene_from(ptgpu_ctx* c, const ptgpu_ctx* src) {
+    if (!c || !src) return PTGPU_E_INVALID;
+    if (c == src) return c->fail(PTGPU_E_INVALID, "load_scene_from: source and destination are the same context");
+    if (!src->scene_loaded) return c->fail(PTGPU_E_STATE, "load_scene_from: the source context has no scene loaded");
+    if (c->persistent != src->persistent) return c->fail(PTGPU_E_INVALID, "load_scene_from: the contexts run different extend kernels");
+    PT_HIP(c, hipSetDevice(c->device));
+    c->scene_loaded = false;
+    // device to device, buffer by buffer: over xGMI between two GPUs of a node, inside HBM on one GPU
+    auto copy = [&](DevBuf& dst, const DevBuf& from) -> int {
+        if (!from.p || !from.bytes) return PTGPU_OK;
+        PT_HIP(c, dst.ensure(from.bytes));
+        if (c->device == src->device) PT_HIP(c, hipMemcpy(dst.p, from.p, from.bytes, hipMemcpyDeviceToDevice));
+        else PT_HIP(c, hipMemcpyPeer(dst.p, c->device, from.p, src->device, from.bytes));
+        return PTGPU_OK;
+    };
+    ptgpu_ctx* d = c;
+    const std::pair<DevBuf*, const DevBuf*> pairs[] = {
+        {&d->nodes, &src->nodes}, {&d->tris, &src->tris}, {&d->nodes4, &src->nodes4}, {&d->tlas, &src->tlas},
+        {&d->instances, &src->instances}, {&d->xforms, &src->xforms}, {&d->objects, &src->objects}, {&d->corners, &src->corners},
+        {&d->texels, &src->texels}, {&d->env, &src->env}, {&d->lut, &src->lut}, {&d->d_object_mesh, &src->d_object_mesh}};
+    for (const auto& pr : pairs) {
+        const int rc = copy(*pr.first, *pr.second);
+        if (rc) return rc;
+    }
+    c->scene = src->scene;  // the scalars; the pointers are set to this context's buffers next
+    c->has_nodes4 = src->has_nodes4;
+    point_scene_at_buffers(c);
+    c->bvh_info = src->bvh_info;
+    c->object_mesh = src->object_mesh;
+    c->max_depth = src->max_depth;
+    std::memcpy(c->scene_min, src->scene_min, 12);
+    std::memcpy(c->scene_max, src->scene_max, 12);
+    c->persist_blocks = 0;
+    // what load_scene reads from the settings is what the SOURCE was loaded with; the rest of this context's settings stand
+    c->scene_settings = src->scene_settings;
+    c->settings.accel_struct_type = src->scene_settings.accel_struct_type;
+    c->settings.program_mode = src->scene_settings.program_mode;
+    c->settings.max_triangles_per_bvh_leaf = src->scene_settings.max_triangles_per_bvh_leaf;
+    c->settings.max_new_rays_per_bounce = src->scene_settings.max_new_rays_per_bounce;
+    c->settings.envmap_rotation = src->scene_settings.envmap_rotation;
+    c->settings.flags = (c->settings.flags & ~PTGPU_FLAG_WIDE_NODES) | (src->scene_settings.flags & PTGPU_FLAG_WIDE_NODES);
+    c->scene_loaded = true;
+    return PTGPU_OK;
+}
+
+uint64_t ptgpu_host_build_count(void) { return pth::host_build_count(); }
 
 int ptgpu_update_camera_transform_state(ptgpu_ctx* c, const float position[3], const float direction[3], const float up[3],
                                         float yfov, float aspect, float znear, float zfar) {
@@ -1446,9 +1024,8 @@ int ptgpu_intersect_rays(ptgpu_ctx* c, uint64_t n, const float* origins, const f
     if (!c || (n && (!origins || !directions || !out))) return PTGPU_E_INVALID;
     if (!c->scene_loaded) return c->fail(PTGPU_E_STATE, "intersect_rays: no scene loaded");
     PT_HIP(c, hipSetDevice(c->device));
-    // rays per pass: 4 Mi unless PTGPU_INTERSECT_CHUNK says otherwise (experiments with launch-sized passes)
-    const char* cap_env = std::getenv("PTGPU_INTERSECT_CHUNK");
-    const uint64_t cap = cap_env ? std::max<uint64_t>(std::strtoull(cap_env, nullptr, 10), 64) : (1u << 22);
+    // rays per pass: 4 Mi unless ptgpu_options.intersect_chunk says otherwise (experiments with launch-sized passes)
+    const uint64_t cap = c->options.intersect_chunk ? std::max<uint64_t>(c->options.intersect_chunk, 64) : (1u << 22);
     const uint64_t K = std::max<uint64_t>(std::min<uint64_t>(std::min<uint64_t>(c->chunk, cap), n), 64);
     int rc = ensure_work_memory(c, 0, 0, K, K);
     if (rc) return rc;

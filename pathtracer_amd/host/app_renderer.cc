@@ -558,15 +558,20 @@ void Renderer::load_scene(const Model& model, const CPUTexture<hdr_pixel>& envma
         if (rc != PTGPU_OK) fail("ptgpu_load_scene", rc);
         return;
     }
-    // every device holds the whole scene (it is read-only and small next to 288 GB): one host thread per device
+    // Every device holds the whole scene (it is read-only and small next to 288 GB), but the acceleration structure is built
+    // ONCE, as the reference builds it once per load_scene (src/renderer.cc:41-64): the first context builds and uploads,
+    // the others copy its device buffers (over xGMI), one host thread per device.
+    const int rc0 = ptgpu_load_scene(ctxs_[0], &m, &e);
+    if (rc0 != PTGPU_OK) fail("ptgpu_load_scene", rc0);
     std::vector<int> rcs(ctxs_.size(), PTGPU_OK);
     std::vector<std::thread> workers;
-    for (size_t k = 0; k < ctxs_.size(); ++k) workers.emplace_back([&, k] { rcs[k] = ptgpu_load_scene(ctxs_[k], &m, &e); });
+    for (size_t k = 1; k < ctxs_.size(); ++k) workers.emplace_back([&, k] { rcs[k] = ptgpu_load_scene_from(ctxs_[k], ctxs_[0]); });
     for (std::thread& t : workers) t.join();
-    for (size_t k = 0; k < ctxs_.size(); ++k)
+    for (size_t k = 1; k < ctxs_.size(); ++k)
         if (rcs[k] != PTGPU_OK)
-            throw std::runtime_error("ptgpu_load_scene failed (" + std::to_string(rcs[k]) + ") on device context " + std::to_string(k) + ": " +
-                                     ptgpu_last_error(ctxs_[k]));
+            throw std::runtime_error("ptgpu_load_scene_from failed (" + std::to_string(rcs[k]) + ") on device context " + std::to_string(k) +
+                                     ": " + ptgpu_last_error(ctxs_[k]));
+    push_settings();  // (a copied scene brings the first context's scene settings along; each device keeps its own sample subset)
 }
 
 void Renderer::render_frame(CPUFrameBuffer& framebuffer) {  // src/renderer.cc:77-123

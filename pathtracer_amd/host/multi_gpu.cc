@@ -33,6 +33,21 @@ void DeviceGroup::fail(const std::string& what) const { throw std::runtime_error
     } while (0)
 
 DeviceGroup::DeviceGroup(const std::vector<int>& devices) : devices_(devices) {
+    // A constructor that throws gets no destructor call: whatever init() had made by then (the library handle, the entry
+    // point table, streams, communicators) is released here, and the caller's current device is put back either way.
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    try {
+        init();
+    } catch (...) {
+        release();
+        if (caller_device >= 0) (void)hipSetDevice(caller_device);
+        throw;
+    }
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+}
+
+void DeviceGroup::init() {
     if (devices_.empty()) fail("no devices");
     int n_visible = 0;
     MG_HIP(hipGetDeviceCount(&n_visible));
@@ -59,27 +74,36 @@ DeviceGroup::DeviceGroup(const std::vector<int>& devices) : devices_(devices) {
     streams_.assign(devices_.size(), nullptr);
     buffers_.assign(devices_.size(), nullptr);
     capacity_.assign(devices_.size(), 0);
+    comms_.assign(devices_.size(), nullptr);
     for (size_t k = 0; k < devices_.size(); ++k) {
         MG_HIP(hipSetDevice(devices_[k]));
         hipStream_t st = nullptr;
         MG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         streams_[k] = st;
     }
-    std::vector<ncclComm_t> comms(devices_.size());
-    MG_NCCL(api_->comm_init_all(comms.data(), static_cast<int>(devices_.size()), devices_.data()));
-    comms_.assign(comms.begin(), comms.end());
+    // (the communicators land in comms_ directly, so that a call that fails half way leaves the ones it made where
+    // release() finds them)
+    static_assert(sizeof(ncclComm_t) == sizeof(void*), "a communicator handle is a pointer");
+    MG_NCCL(api_->comm_init_all(reinterpret_cast<ncclComm_t*>(comms_.data()), static_cast<int>(devices_.size()), devices_.data()));
 }
 
-DeviceGroup::~DeviceGroup() {
+void DeviceGroup::release() noexcept {
     for (size_t k = 0; k < devices_.size(); ++k) {
         (void)hipSetDevice(devices_[k]);
-        if (k < comms_.size() && comms_[k] && api_) (void)api_->comm_destroy(static_cast<ncclComm_t>(comms_[k]));
+        if (k < comms_.size() && comms_[k] && api_ && api_->comm_destroy) (void)api_->comm_destroy(static_cast<ncclComm_t>(comms_[k]));
         if (k < buffers_.size() && buffers_[k]) (void)hipFree(buffers_[k]);
         if (k < streams_.size() && streams_[k]) (void)hipStreamDestroy(static_cast<hipStream_t>(streams_[k]));
     }
+    comms_.clear();
+    buffers_.clear();
+    streams_.clear();
     delete api_;
+    api_ = nullptr;
     if (rccl_) dlclose(rccl_);
+    rccl_ = nullptr;
 }
+
+DeviceGroup::~DeviceGroup() { release(); }
 
 float* DeviceGroup::sums(size_t k, size_t n_floats) {
     if (capacity_[k] < n_floats) {

@@ -28,6 +28,8 @@ class DeviceGroup {
 
   private:
     [[noreturn]] void fail(const std::string& what) const;
+    void init();               // everything the constructor makes; may throw half way
+    void release() noexcept;   // frees whatever exists (also after a partial init)
     std::vector<int> devices_;
     std::vector<void*> streams_;
     std::vector<float*> buffers_;

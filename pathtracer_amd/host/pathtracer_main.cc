@@ -106,7 +106,8 @@ int main(int argc, char* argv[]) {
             model = loader.constructModel();
         }
         CPUTexture<hdr_pixel> environment_texture;
-        if (args.env == "white") environment_texture = CPUTexture<hdr_pixel>::create_white_texture();
+        // an empty path is the default environment too, and the default is white (src/arguments.cc:140-144, arguments.h:32)
+        if (args.env == "white" || args.env.empty()) environment_texture = CPUTexture<hdr_pixel>::create_white_texture();
         else if (args.env == "black") environment_texture = CPUTexture<hdr_pixel>::create_black_texture();
         else environment_texture = CPUTexture<hdr_pixel>(std::filesystem::path(args.env));
         std::cout << "loaded in " << ms_since(start) << " ms." << '\n';
@@ -139,6 +140,8 @@ int main(int argc, char* argv[]) {
             const ptgpu_stats& s = viewer.renderer().last_stats();
             std::cout << "rays " << s.rays << " samples " << s.camera_samples << " gpu_ms " << s.total_ms << " extend_ms " << s.extend_ms
                       << " shade_ms " << s.shade_ms << " Mrays/s " << (s.total_ms > 0 ? s.rays / s.total_ms / 1e3 : 0.0) << '\n';
+            // (one, however many devices render: the first builds, the others copy its device buffers)
+            std::cout << "acceleration structure builds " << ptgpu_host_build_count() << " devices " << args.gpus << '\n';
         }
 
         start = std::chrono::high_resolution_clock::now();

@@ -152,6 +152,28 @@ class Renderer:
         self._check(self._L.ptgpu_load_scene(self._h, C.byref(cm), env_ref))
         self._model = model
 
+    def load_scene_from(self, source: "Renderer") -> None:
+        """``ptgpu_load_scene_from``: take over the scene another renderer has loaded, device to device — the acceleration
+        structure is built once however many GPUs render it."""
+        self._check(self._L.ptgpu_load_scene_from(self._h, source._h))
+        self._model = source._model
+        self._settings = self.get_render_settings()
+
+    def set_options(self, **fields) -> None:
+        """``ptgpu_set_options``: fields of ``abi.Options`` by name; the others keep their current value."""
+        o = abi.Options()
+        self._check(self._L.ptgpu_get_options(self._h, C.byref(o)))
+        for k, v in fields.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        self._check(self._L.ptgpu_set_options(self._h, C.byref(o)))
+
+    def get_options(self) -> abi.Options:
+        o = abi.Options()
+        self._check(self._L.ptgpu_get_options(self._h, C.byref(o)))
+        return o
+
     def update_camera_transform_state(self, position, direction, up, perspective: Perspective) -> None:
         p = np.ascontiguousarray(position, np.float32)
         d = np.ascontiguousarray(direction, np.float32)

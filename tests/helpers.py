@@ -24,8 +24,11 @@ def make_oracle(model, env, st: RenderSettings, width, height, math_mode=ob.MATH
     return s
 
 
-def make_gpu(model, env, st: RenderSettings, width, height, device=0):
+def make_gpu(model, env, st: RenderSettings, width, height, device=0, **options):
+    """`options`: fields of the library's tuning record (ptgpu_options) by name, e.g. traverse_waves=6."""
     r = Renderer(device)
+    if options:
+        r.set_options(**options)
     r.set_render_settings(st)
     r.load_scene(model, env)
     cam = model.cameras[0]

@@ -10,7 +10,7 @@ import pytest
 
 import helpers as H
 from oracle import binding as ob
-from pathtracer_amd import scenes
+from pathtracer_amd import abi, scenes
 from pathtracer_amd.renderer import CPUFrameBuffer, Renderer, RenderSettings
 
 pytestmark = pytest.mark.gpu
@@ -298,7 +298,7 @@ def test_wide_nodes_give_the_same_results(tiny, materials, scene, as_type):
 
 def test_both_forms_of_the_wide_kernel_agree(materials):
     """The four-wide traversal kernel exists in two forms — six or seven workgroups per CU, with LDS stacks of 12 or 10
-    entries and 192 or 176 cached nodes; which one runs is chosen by the size of the scene (PTGPU_TRAVERSE_WAVES overrides).
+    entries and 192 or 176 cached nodes; which one runs is chosen by the size of the scene (ptgpu_options.traverse_waves overrides).
     Same tree, same steps per ray: closest-hit records, any-hit flags and ray counts are equal to the bit, on a deep mesh
     (stack entries beyond the LDS part) and on the scene with every material feature."""
     rng = np.random.default_rng(5)
@@ -310,13 +310,10 @@ def test_both_forms_of_the_wide_kernel_agree(materials):
     w, h = 200, 120
     for model, env in ((scenes.stress_mesh(400_000), None), materials):
         results = []
-        for waves in ("6", "7"):
-            os.environ["PTGPU_TRAVERSE_WAVES"] = waves
-            try:
-                g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=True), w, h)
-            finally:
-                os.environ.pop("PTGPU_TRAVERSE_WAVES", None)
+        for waves in (6, 7):
+            g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=True), w, h, traverse_waves=waves)
             img, st = H.gpu_render(g, w, h)
+            assert st.traverse_workgroups_per_cu == waves
             results.append((g.intersect_rays(org, d), g.intersect_rays(org, d, any_flags)["hit"], int(st.rays), img))
         (c6, a6, r6, i6), (c7, a7, r7, i7) = results
         exact, _ = H.hits_equal(c6, c7)
@@ -327,7 +324,7 @@ def test_both_forms_of_the_wide_kernel_agree(materials):
 @pytest.mark.parametrize("wide", [False, True])
 def test_phase_vote_of_the_traversal_kernel_changes_no_result(materials, wide):
     """Which phase a traversal wavefront runs next (node steps or leaf steps) is decided by a vote in which the lanes at
-    leaves carry a weight chosen at scene load (1, or 4 for large scenes; PTGPU_LEAF_VOTE overrides).  It schedules the
+    leaves carry a weight chosen at scene load (1, or 4 for large scenes; ptgpu_options.leaf_vote overrides).  It schedules the
     lanes and nothing else: hit records, any-hit flags and ray counts are equal to the bit for every weight."""
     rng = np.random.default_rng(11)
     n = 30000
@@ -338,17 +335,106 @@ def test_phase_vote_of_the_traversal_kernel_changes_no_result(materials, wide):
     w, h = 160, 96
     model, env = materials
     results = []
-    for vote in ("1", "4", "16"):
-        os.environ["PTGPU_LEAF_VOTE"] = vote
-        try:
-            g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=wide), w, h)
-        finally:
-            os.environ.pop("PTGPU_LEAF_VOTE", None)
+    for vote in (1, 4, 16):
+        g = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=5, wide=wide), w, h, leaf_vote=vote)
         _, st = H.gpu_render(g, w, h)
         results.append((g.intersect_rays(org, d), g.intersect_rays(org, d, any_flags)["hit"], int(st.rays)))
     for c, a, r in results[1:]:
         exact, _ = H.hits_equal(results[0][0], c)
         assert exact.all() and (a == results[0][1]).all() and r == results[0][2]
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_scene_copied_from_another_context(materials, wide):
+    """A renderer that drives several GPUs builds the acceleration structure once (the reference builds it once per
+    load_scene, src/renderer.cc:41-64): the first context loads the scene, the others take it over device to device
+    (ptgpu_load_scene_from).  The copy renders what the original renders — hit records and ray counts to the bit, its own
+    sample subset — no second build happens, and the copy outlives its source."""
+    model, env = materials
+    w, h = 160, 96
+    st = H.settings(program=2, spp=4, bounces=4, wide=wide)
+    a = H.make_gpu(model, env, st, w, h)
+    builds = a._L.ptgpu_host_build_count()
+    b = Renderer(0)
+    b.set_render_settings(H.settings(program=0, spp=4, bounces=4, begin=1, step=2))  # (program / wide flag come with the scene)
+    b.load_scene_from(a)
+    assert a._L.ptgpu_host_build_count() == builds
+    got = b.get_render_settings()
+    assert (got.programMode, got.wideNodes, got.sampleBegin, got.sampleStep) == (st.programMode, wide, 1, 2)
+    m, o = a.get_camera_raw()
+    b.set_camera_raw(m, o)
+    exact, _ = H.hits_equal(a.render_hits(w, h), b.render_hits(w, h))
+    assert exact.all()
+    assert a.bvh_info(0).checksum == b.bvh_info(0).checksum and np.array_equal(a.get_scene_bound()[0], b.get_scene_bound()[0])
+    # the copy renders samples 1 and 3, the original samples 0 and 2 and then all four: partial sums add up, ray counts too
+    import torch
+    from pathtracer_amd.distributed import subset_settings
+    buf_a = torch.zeros((h, w, 4), device="cuda")
+    buf_b = torch.zeros((h, w, 4), device="cuda")
+    a.set_render_settings(subset_settings(st, 0, 2))
+    sa = a.render_frame_sums(w, h, buf_a.data_ptr())
+    sb = b.render_frame_sums(w, h, buf_b.data_ptr())
+    a.set_render_settings(st)
+    img, s_all = H.gpu_render(a, w, h)
+    assert sa.rays + sb.rays == s_all.rays and sa.camera_samples == sb.camera_samples == w * h * 2
+    both = ((buf_a + buf_b)[..., :3] / 4).cpu().numpy()
+    assert np.allclose(both, img[..., :3], rtol=2e-5, atol=2e-6)
+    a.close()   # the copy owns its buffers
+    exact, _ = H.hits_equal(H.make_oracle(model, env, st, w, h).render_hits(w, h), b.render_hits(w, h))
+    assert exact.mean() >= (0.9999 if wide else 1.0)
+    with pytest.raises(RuntimeError, match="no scene loaded"):
+        Renderer(0).load_scene_from(Renderer(0))
+
+
+def test_options_change_the_schedule_not_the_result(tiny):
+    """ptgpu_options: the batch size and the pool bound cut the same frame into other launches — the same rays, the same
+    picture; values outside their range are refused; a new context reports what it was given."""
+    model, env = tiny
+    w, h = 96, 54
+    st = H.settings(program=2, spp=8, bounces=4)
+    base = H.make_gpu(model, env, st, w, h)
+    img, s0 = H.gpu_render(base, w, h)
+    small = H.make_gpu(model, env, st, w, h, chunk_rays=8192, pool_gib=1)
+    o = small.get_options()
+    assert (o.chunk_rays, o.pool_gib) == (8192, 1)
+    img2, s1 = H.gpu_render(small, w, h)
+    assert s1.rays == s0.rays and s1.extend_launches > s0.extend_launches
+    assert np.allclose(img, img2, rtol=2e-5, atol=2e-6)
+    simple = H.make_gpu(model, env, st, w, h, flags=abi.OPT_EXTEND_SIMPLE)   # one ray per lane: the cross-check kernel
+    img3, s2 = H.gpu_render(simple, w, h)
+    assert s2.rays == s0.rays and s2.traverse_workgroups_per_cu == 0 and np.allclose(img, img3, rtol=2e-5, atol=2e-6)
+    for bad in (dict(chunk_rays=100), dict(traverse_waves=5), dict(leaf_vote=99), dict(flags=1 << 20), dict(pool_gib=100000)):
+        with pytest.raises(RuntimeError):
+            base.set_options(**bad)
+    # switching the extend kernel under a loaded scene unloads it (the scene was laid out for the other kernel)
+    base.set_options(flags=abi.OPT_EXTEND_SIMPLE)
+    with pytest.raises(RuntimeError, match="nullptr"):
+        base.render_frame(CPUFrameBuffer(w, h))
+
+
+def test_axis_parallel_rays_over_wide_nodes(materials):
+    """Rays with a zero direction component take the exact (select-form) box test in the four-wide kernel; unused child
+    slots of a node hold an inverted box, which that symmetric test must not take for a real one.  Axis-parallel rays over
+    binary and four-wide nodes give the oracle's closest hits."""
+    model, env = materials
+    st = H.settings(program=0)
+    lo, hi = model.vertices["position"].min(axis=0), model.vertices["position"].max(axis=0)
+    rng = np.random.default_rng(3)
+    n = 30000
+    org = rng.uniform(lo - 1.0, hi + 1.0, (n, 3)).astype(np.float32)
+    axis = rng.integers(0, 3, n)
+    d = np.zeros((n, 3), np.float32)
+    d[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    two = rng.uniform(size=n) < 0.3            # some with two zero components, the rest with one
+    other = (axis + 1) % 3
+    d[np.arange(n)[~two], other[~two]] = 0.6
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ref = H.make_oracle(model, env, st, 64, 64).intersect_rays(org, d)
+    assert ref["hit"].sum() > 500
+    for wide in (False, True):
+        g = H.make_gpu(model, env, H.settings(program=0, wide=wide), 64, 64)
+        exact, _ = H.hits_equal(ref, g.intersect_rays(org, d))
+        assert exact.mean() >= (0.9999 if wide else 1.0), (wide, int((~exact).sum()))
 
 
 @pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
@@ -387,7 +473,7 @@ def test_many_objects_instance_tree(wide):
     """Hundreds of instances: the instance pass culls with a tree over the bounds' boxes instead of testing every bound
     for every ray.  The candidate lists must be the ones the full scan makes: with binary nodes everything equals the
     oracle (hit records of camera rays and of random closest / any-hit rays bit for bit, ray counts, instances entered,
-    frames within the summation tolerance) — and equals this library's own full scan (PTGPU_TLAS=linear)."""
+    frames within the summation tolerance) — and equals this library's own full scan (PTGPU_OPT_LINEAR_TLAS)."""
     model, env = scenes.many_objects(300), scenes.synthetic_env()
     w, h = 192, 108
     st = H.settings(program=2, spp=2, bounces=3, wide=wide)
@@ -419,11 +505,7 @@ def test_many_objects_instance_tree(wide):
         assert exact.all(), int((~exact).sum())
     else:
         assert (got["hit"] == ref["hit"]).mean() >= 0.9999 and exact[flags == 0].mean() >= 0.9999
-    os.environ["PTGPU_TLAS"] = "linear"
-    try:
-        lin = H.make_gpu(model, env, st, w, h)
-    finally:
-        del os.environ["PTGPU_TLAS"]
+    lin = H.make_gpu(model, env, st, w, h, flags=abi.OPT_LINEAR_TLAS)
     exact, _ = H.hits_equal(lin.intersect_rays(org, d, flags), got)
     assert exact.all()
     _, sl = lin.render_counted(w, h)
@@ -570,6 +652,14 @@ def test_error_behaviour(tiny):
     bad.indices[5] = 10 ** 6
     with pytest.raises(RuntimeError, match="out of range"):
         r.load_scene(bad, env)
+    # coordinates the builders cannot order (not-a-number, infinite, or so large that box areas overflow) are refused
+    for value in (np.nan, np.inf, 1e20):
+        bad = scenes.tiny_scene()
+        bad.vertices["position"][3, 1] = value
+        for wide in (False, True):
+            r.set_render_settings(H.settings(program=2, wide=wide))
+            with pytest.raises(RuntimeError, match="not finite or beyond"):
+                r.load_scene(bad, env)
     with pytest.raises(RuntimeError):
         r.set_render_settings(RenderSettings(1, 1, 0, 8, 0.0, 7, 1))  # program mode out of range
     with pytest.raises(RuntimeError):
@@ -609,8 +699,9 @@ def test_frame_beyond_the_packed_slot_range(materials):
 
 def test_full_size_readme_frame_properties():
     """BASELINE configuration 3 at full resolution (800x600, 6 bounces) on the ~1.2M-triangle stand-in,
-    at 2 spp to bound the run time: a 16-row band must match the oracle, the frame must be finite, and
-    rendering the two samples separately must add up to the 2-spp frame (linearity in the sample set)."""
+    at 2 spp to bound the run time: EVERY pixel of the frame must match the oracle's frame with equal ray counts
+    (binary nodes, the reference's visiting order), and rendering the two samples separately must add up to the
+    2-spp frame (linearity in the sample set)."""
     import torch
     from pathtracer_amd import image_io
     from pathtracer_amd.distributed import subset_settings
@@ -622,9 +713,11 @@ def test_full_size_readme_frame_properties():
     img, s = H.gpu_render(g, w, h)
     assert np.isfinite(img).all() and s.camera_samples == w * h * 2 and s.rays > s.camera_samples
     o = H.make_oracle(model, env, st, w, h)
-    band, so = o.render_frame(w, h, rows=(292, 308))
-    d = np.abs(img[292:308, :, :3] - band[292:308, :, :3])
-    assert (d <= 2e-5 * np.maximum(1.0, band[292:308, :, :3])).all(), d.max()
+    full, so = o.render_frame(w, h)
+    assert s.rays == so.rays, (s.rays, so.rays)
+    d = np.abs(img[..., :3] - full[..., :3])
+    assert (d <= 2e-5 * np.maximum(1.0, full[..., :3])).all(), (d.max(), np.argwhere(d > 2e-5 * np.maximum(1.0, full[..., :3]))[:4])
+    assert (img[..., 3] == 1).all()
     parts = []
     for k in range(2):
         buf = torch.zeros((h, w, 4), device="cuda")
@@ -633,12 +726,12 @@ def test_full_size_readme_frame_properties():
         parts.append(buf)
     both = ((parts[0] + parts[1])[..., :3] / 2).cpu().numpy()
     assert np.allclose(both, img[..., :3], rtol=1e-5, atol=1e-6)
-    # the same frame over four-wide nodes (the benchmark's setting): same rays, same band
+    # the same frame over four-wide nodes (the benchmark's setting): same rays, the whole frame again
     gw = H.make_gpu(model, env, H.settings(program=2, spp=2, bounces=6, wide=True), w, h)
     img_w, sw = H.gpu_render(gw, w, h)
     assert abs(int(sw.rays) - int(s.rays)) <= 1e-6 * s.rays   # a tie in distance between two triangles may fall the other way
-    d = np.abs(img_w[292:308, :, :3] - band[292:308, :, :3])
-    assert (d > 2e-5 * np.maximum(1.0, band[292:308, :, :3])).any(axis=-1).mean() <= 1e-4
+    d = np.abs(img_w[..., :3] - full[..., :3])
+    assert (d > 2e-5 * np.maximum(1.0, full[..., :3])).any(axis=-1).mean() <= 1e-4
     exact, _ = H.hits_equal(g.render_hits(w, h), gw.render_hits(w, h))
     assert exact.mean() >= 0.99999
 
@@ -647,7 +740,7 @@ def test_full_size_ambient_occlusion_properties():
     """BASELINE configuration 2 at full size (1920x1080, 64 spp, 8 occlusion rays, 1 bounce) under the white
     environment.  Every path contributes a multiple of 1/8 (ray_program.cc:212-224: payload 1/r per occlusion
     ray, returned on a miss), so 8 * spp * pixel must be an integer exactly; the ray count follows from the number
-    of primary hits; a band of rows equals the oracle; sample subsets add up."""
+    of primary hits; the whole frame at 4 spp equals the oracle's; sample subsets add up."""
     import torch
     from pathtracer_amd.distributed import subset_settings
     model = scenes.readme_standin(detail=1.0)
@@ -663,13 +756,20 @@ def test_full_size_ambient_occlusion_properties():
     primary_hits = (s.rays - s.camera_samples) // r
     # a pixel whose samples all missed is exactly 1; every primary hit removes its sample's direct contribution
     assert 0 < primary_hits < s.camera_samples
-    band_rows = (536, 540)
-    st_band = H.settings(program=1, spp=4, bounces=1, newrays=r)
-    g.set_render_settings(st_band)
-    img4, _ = H.gpu_render(g, w, h)
-    o = H.make_oracle(model, None, st_band, w, h)
-    band, _ = o.render_frame(w, h, rows=band_rows)
-    assert np.array_equal(img4[band_rows[0]:band_rows[1], :, :3], band[band_rows[0]:band_rows[1], :, :3])
+    # the whole 1920x1080 frame at 4 spp against the oracle: sums of multiples of 1/8 are exact, so the frames are EQUAL
+    st4 = H.settings(program=1, spp=4, bounces=1, newrays=r)
+    g.set_render_settings(st4)
+    img4, s4 = H.gpu_render(g, w, h)
+    o = H.make_oracle(model, None, st4, w, h)
+    full4, so4 = o.render_frame(w, h)
+    assert s4.rays == so4.rays, (s4.rays, so4.rays)
+    assert np.array_equal(img4[..., :3], full4[..., :3]), np.argwhere(img4[..., 0] != full4[..., 0])[:4]
+    # four-wide nodes: an any-hit ray may report another triangle, but whether it is occluded does not depend on the order
+    gw = H.make_gpu(model, None, H.settings(program=1, spp=4, bounces=1, newrays=r, wide=True), w, h)
+    img4w, s4w = H.gpu_render(gw, w, h)
+    assert abs(int(s4w.rays) - int(so4.rays)) <= 1e-6 * so4.rays
+    assert (img4w[..., 0] != full4[..., 0]).mean() <= 1e-4
+    del gw
     parts = []
     for k in range(2):
         buf = torch.zeros((h, w, 4), device="cuda")

@@ -71,6 +71,10 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
     r = run("-f", scene, "-o", tmp_path / "o.hdr", "--width", 16, "--height", 8)
     assert r.returncode == 1 and "ptgpu_create failed" in r.stderr
     assert not (tmp_path / "o.hdr").exists()
+    # an empty environment path is the default (white) environment, not a file to open (src/arguments.cc:140-144): the run
+    # gets past the environment and fails at the same place
+    r = run("-f", scene, "-e", "", "-o", tmp_path / "o.hdr", "--width", 16, "--height", 8)
+    assert r.returncode == 1 and "ptgpu_create failed" in r.stderr and "loaded in" in r.stdout
 
 
 @needs_cli
@@ -132,6 +136,12 @@ def test_cli_repairs_out_of_range_values_like_the_reference(tmp_path):
     r = run("-f", scene, "-p", 1, "-a", 1, "-s", 1, "-b", 0, "-r", 0, "-m", 1, "--width", 48, "--height", 32, "-o", b)
     assert r.returncode == 0, r.stderr
     assert np.array_equal(read_png(a), read_png(b))
+    # -e "" is the white default environment (src/arguments.cc:140-144, arguments.h:32)
+    r = run("-f", scene, "-p", 3, "-s", 2, "-b", 2, "--seed", 3, "-e", "", "--width", 48, "--height", 32, "-o", a)
+    assert r.returncode == 0, r.stderr
+    r = run("-f", scene, "-p", 3, "-s", 2, "-b", 2, "--seed", 3, "-e", "white", "--width", 48, "--height", 32, "-o", b)
+    assert r.returncode == 0, r.stderr
+    assert np.abs(read_png(a).astype(int) - read_png(b).astype(int)).max() <= 1
     r = run("-f", scene, "-p", 1, "--width", 0, "--height", -4, "-o", a)
     assert r.returncode == 0, r.stderr
     assert read_png(a).shape == (1, 1, 4)

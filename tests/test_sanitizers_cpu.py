@@ -49,3 +49,8 @@ def test_host_readers_under_sanitizers(tmp_path):
 def test_tree_builder_under_sanitizers():
     out = run([tool("san_bvh")])
     assert "far leaf 1 form 0" in out and "flat leaf 8 form 2" in out and "empty leaf 64 form 1" in out
+    # the whole scene build with four-wide nodes (collapse, quantisation, top nodes, instance tree) ran and its invariants held:
+    # 24 regular builds + 24 on coordinates that validation refuses (those must stay inside their arrays all the same)
+    last = out.strip().splitlines()[-1]
+    assert last.startswith("scene builds: wide nodes walked ") and last.endswith("builds 48"), last
+    assert int(last.split()[5].rstrip(",")) > 10000

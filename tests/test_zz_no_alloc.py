@@ -53,3 +53,43 @@ def test_static_entry_point_equals_intersect_rays(wide):
     assert ref.tobytes() == got.tobytes()
     with pytest.raises(PtgpuError, match="built-in work array holds"):
         gpu.intersect_rays_static(abi.STATIC_MAX_RAYS + 1, 8, 8, 0, 8)
+
+
+def test_static_entry_point_against_the_oracle():
+    """The same records against the CPU oracle (not only against the allocating entry point): closest-hit and any-hit rays,
+    binary nodes, so the any-hit records are the reference's too."""
+    model = scenes.readme_standin(detail=0.05)
+    st = H.settings(program=0)
+    gpu = H.make_gpu(model, None, st, 64, 64)
+    orc = H.make_oracle(model, None, st, 64, 64)
+    o, d, any_hit = random_rays(model, 40_000, 11)
+    got = static_hits(gpu, o, d, any_hit)
+    ref = orc.intersect_rays(o, d, any_hit)
+    exact, _ = H.hits_equal(ref, got)
+    assert ref["hit"].sum() > 1000 and exact.all(), f"{(~exact).sum()} of {len(o)} records differ from the oracle's"
+
+
+def test_static_entry_point_on_a_caller_stream_without_waiting():
+    """wait = 0 on a stream of the caller's: the call returns after queueing, the records are there once the stream has been
+    waited for, and the device's free memory is the same before and after (nothing was allocated on the way)."""
+    import torch
+    model = scenes.readme_standin(detail=0.05)
+    gpu = H.make_gpu(model, None, H.settings(program=0, wide=True), 64, 64)
+    o, d, any_hit = random_rays(model, 50_000, 21)
+    ref = gpu.intersect_rays(o, d, any_hit)
+    n = len(o)
+    t_o, t_d, t_a = torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), torch.from_numpy(any_hit).cuda()
+    out = torch.zeros(n * 8, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    gpu.intersect_rays_static(n, t_o.data_ptr(), t_d.data_ptr(), t_a.data_ptr(), out.data_ptr())  # (first call on this context)
+    out.zero_()
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        gpu.intersect_rays_static(n, t_o.data_ptr(), t_d.data_ptr(), t_a.data_ptr(), out.data_ptr(), stream=stream.cuda_stream, wait=False)
+    stream.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
+    got = out.cpu().numpy().view(abi.HIT_DTYPE)
+    assert ref.tobytes() == got.tobytes()
