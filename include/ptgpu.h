@@ -167,7 +167,7 @@ typedef struct ptgpu_settings {
  * every measurement in this repository was taken with unless it says otherwise.  A new context starts from the
  * PTGPU_* environment variables of the same names (PTGPU_CHUNK, PTGPU_POOL_GIB, PTGPU_TRAVERSE_WAVES, PTGPU_LEAF_VOTE,
  * PTGPU_BUILD_THREADS, PTGPU_INTERSECT_CHUNK, PTGPU_PERSIST_BLOCKS, PTGPU_EXTEND=simple, PTGPU_WIDE_SPLITS=reference,
- * PTGPU_WIDE_COLLAPSE=greedy, PTGPU_TLAS=linear, PTGPU_VERBOSE=1|2), read once in ptgpu_create so that measurement
+ * PTGPU_WIDE_COLLAPSE=greedy, PTGPU_TLAS=linear, PTGPU_LEAF_RECORDS=0|1, PTGPU_VERBOSE=1|2), read once in ptgpu_create so that measurement
  * scripts can alternate settings around an unchanged caller; ptgpu_set_options replaces them. */
 typedef struct ptgpu_options {
     uint32_t chunk_rays;      /* camera samples per batch, 1024 .. 2^28 (default 2^26): sizes the ray pools and the launches */
@@ -185,6 +185,11 @@ typedef struct ptgpu_options {
 #define PTGPU_OPT_LINEAR_TLAS 8u        /* every ray tests every instance bound, however many instances */
 #define PTGPU_OPT_VERBOSE 16u           /* diagnostics on stderr */
 #define PTGPU_OPT_VERBOSE_LAUNCHES 32u  /* one line per launch on stderr */
+/* Leaves of the four-wide trees as one aligned 64-byte record each (one memory sector per leaf visit instead of two or
+ * three) — by default for scenes whose geometry is beyond the caches; these two force it on or off (PTGPU_LEAF_RECORDS=1|0).
+ * The same hits to the bit either way. */
+#define PTGPU_OPT_LEAF_RECORDS 64u
+#define PTGPU_OPT_NO_LEAF_RECORDS 128u
 
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */

@@ -60,6 +60,19 @@ struct alignas(16) TriQ {         // 48 B
     uint32_t leaf_count;          // triangles of the leaf from this one on (1 = last of its leaf)
     uint32_t pad;
 };
+// One leaf of a four-wide tree as ONE aligned 64-byte record (large scenes, where the traversal is limited by the number of
+// memory sectors it touches): the leaf's one or two triangles as their three or four distinct corner positions.  The first
+// triangle is (v0, v1, v2) in the mesh's corner order; the second, when it shares an edge with the first, is three of
+// v0..v3 picked by 2-bit selectors.  A leaf whose two triangles share no edge takes two records, the first flagged
+// "continues".  The kernel forms p2 - p1 and p3 - p1 itself, the same two binary32 subtractions the triangle test of the
+// reference starts with (acceleration_structure.cc:24-25), so the hit is the one the 48-byte records give, to the bit.
+struct alignas(64) Leaf64 {
+    float v[4][3];
+    uint32_t index0, index1;      // triangleIndex of the first and the second triangle
+    uint32_t info;                // bit 0: a second triangle; bit 1: the leaf continues in the next record;
+                                  // bits 8-9, 10-11, 12-13: which of v0..v3 are the second triangle's p1, p2, p3
+    uint32_t pad;
+};
 struct alignas(16) DevInstance {  // 64 B
     float dop[14];                // (min,max) for the 7 axes
     uint32_t object_index;
@@ -125,6 +138,7 @@ struct SceneDev {
     uint32_t n_tlas;              // its node count
     const Node4* nodes4;          // four-wide form of the same trees, or null: the persistent kernel then walks `nodes`
     uint32_t n_top_nodes4;        // likewise for nodes4
+    const Leaf64* leaves64;       // leaves of the four-wide trees as 64-byte records, or null: nodes4 refers to `tris`
     uint32_t seven_waves;         // the four-wide traversal kernel runs in its seven-workgroups-per-CU form (shorter LDS stack)
     uint32_t leaf_vote;           // weight of the lanes that hold a leaf when the traversal kernel chooses its next phase (1 or 4)
     int32_t env_w, env_h;

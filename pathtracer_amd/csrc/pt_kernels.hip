@@ -654,7 +654,8 @@ enum : uint32_t { F_ANY = 1u, F_CULL = 2u, F_SLOW = 4u, F_BHIT = 8u, F_LAST = 16
 // XF_LDS: every instance transform of the scene is in the kernel's LDS copy, so a transform is read with LDS instructions
 // (no work for the vector memory path's address unit, and its waits do not cover the loads from memory in flight).
 // XF_MANY (seven-wave form only): twice the transforms in LDS, paid for with fewer cached nodes.
-template <bool COUNT, bool WIDE, bool SEVEN, bool XF_LDS, bool XF_MANY = false>
+// LEAF64 (four-wide forms): leaves are aligned 64-byte records (Leaf64) instead of runs of 48-byte triangles.
+template <bool COUNT, bool WIDE, bool SEVEN, bool XF_LDS, bool XF_MANY = false, bool LEAF64 = false>
 __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* __restrict__ ray_o,
                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
@@ -678,6 +679,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
     TraceCount cnt{};
     static_assert(kTopNodes4 <= kTopNodes && sizeof(Node4) == sizeof(NodeQ), "the four-wide node cache fits the same LDS array");
     static_assert(!SEVEN || WIDE, "the seven-wave budget is for the four-wide kernel");
+    static_assert(!LEAF64 || WIDE, "leaf records belong to the four-wide kernels");
     // Which phase runs when lanes wait at nodes and at leaves: node steps while (lanes at nodes) >= (lanes at leaves) * leaf_vote.
     // With a weight of 4 a leaf step runs for as few as a fifth of the traversing lanes: the lanes it releases go back to the node
     // steps, which are most of the work of a deep closest-hit traversal (readme frame: traversal -1.5 %, binary nodes -2.2 %,
@@ -1033,7 +1035,50 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
             // ================= triangle tests for the lanes that hold a leaf =================
             PT_BURST_UNROLL
             for (int burst = 0;;) {
-                if (WIDE && is_leaf(cur)) {
+                if (WIDE && LEAF64 && is_leaf(cur)) {
+                    // One aligned 64-byte record a step: the leaf's one or two triangles as their distinct corners.  The edges
+                    // p2 - p1 and p3 - p1 are formed here, by the same two subtractions the 48-byte records were made with.
+                    if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
+                    PT_PRIO_UP;
+                    const float4* lp = reinterpret_cast<const float4*>(sc.leaves64 + (cur & ~PT_LEAF_BIT));
+                    const float4 a = lp[0], b = lp[1], c = lp[2], m = lp[3];
+                    const uint32_t top = peek();
+                    PT_PRIO_DOWN;
+                    const f3 v0 = f3{a.x, a.y, a.z}, v1 = f3{a.w, b.x, b.y}, v2 = f3{b.z, b.w, c.x}, v3 = f3{c.y, c.z, c.w};
+                    const uint32_t info = __float_as_uint(m.z);
+                    float A, B, t;
+                    bool bf;
+                    const bool ok = ray_triangle(o, d, v0, v1 - v0, v2 - v0, (flags & F_CULL) != 0, A, B, t, bf);
+                    bool stop = false;
+                    if (ok && !(t < 0.0f) && !(t >= h_t)) {
+                        h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                        h_tri = __float_as_uint(m.x);
+                        stop = (flags & F_ANY) != 0;
+                    }
+                    if (!stop && (info & 1u)) {
+                        if (COUNT) ++cnt.tris;
+                        auto corner = [&](uint32_t sel) {  // v0..v3 by a 2-bit selector
+                            const bool hi = (sel & 2u) != 0, odd = (sel & 1u) != 0;
+                            const f3 lo_pair = odd ? v1 : v0, hi_pair = odd ? v3 : v2;
+                            return hi ? hi_pair : lo_pair;
+                        };
+                        const f3 p1 = corner(info >> 8), p2 = corner(info >> 10), p3 = corner(info >> 12);
+                        const bool ok2 = ray_triangle(o, d, p1, p2 - p1, p3 - p1, (flags & F_CULL) != 0, A, B, t, bf);
+                        if (ok2 && !(t < 0.0f) && !(t >= h_t)) {
+                            h_A = A; h_B = B; h_t = t; h_hit = true; h_back = bf;
+                            h_tri = __float_as_uint(m.y);
+                            stop = (flags & F_ANY) != 0;
+                        }
+                    }
+                    if (stop) {
+                        cur = PT_NO_NODE;
+                    } else if (info & 2u) {
+                        cur = cur + 1u;
+                    } else {
+                        pop_to(top);
+                    }
+                }
+                if (WIDE && !LEAF64 && is_leaf(cur)) {
                     // Two triangles a step: the trees of this layout have leaves of at most two, and fetching both at once
                     // takes one of the two dependent round trips out of a leaf visit.  (The record after the last
                     // triangle of the array is padding.)  Tested in leaf order, so the first found still wins a tie.
@@ -1116,26 +1161,26 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 for (int k = 0; k < 6; ++k) atomicAdd(&counters->census[ph][k], static_cast<unsigned long long>(cnt.census[ph][k]));
     }
 }
-template <bool COUNT, bool WIDE, bool XF_LDS = false>
+template <bool COUNT, bool WIDE, bool XF_LDS = false, bool LEAF64 = false>
 __global__ PT_EXTEND_BOUNDS void traverse_kernel(SceneDev sc, const float4* __restrict__ ray_o,
                                                  const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                  float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                  uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
                                                  uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                                  TraceCounters* counters) {
-    traverse_body<COUNT, WIDE, false, XF_LDS>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+    traverse_body<COUNT, WIDE, false, XF_LDS, false, LEAF64>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 // The four-wide kernel at seven wavefronts per SIMD (72 registers, 22 KB of LDS per workgroup).  Scenes that the caches
 // hold are limited by the latency of a step, and a seventh wavefront hides more of it (2.5-4 % faster); scenes that are
 // limited by the gather path (the 10 M-triangle mesh) and the binary layout run 4-7 % slower that way and keep six.
-template <bool COUNT, bool XF_LDS = false, bool XF_MANY = false>
+template <bool COUNT, bool XF_LDS = false, bool XF_MANY = false, bool LEAF64 = false>
 __global__ __launch_bounds__(kBlock, PT_SEVEN_WAVES) void traverse_kernel7(SceneDev sc, const float4* __restrict__ ray_o,
                                                               const float4* __restrict__ ray_d, uint32_t n, CandQueue cand,
                                                               float4* __restrict__ hit0, uint32_t* __restrict__ hit1,
                                                               uint32_t* __restrict__ spill, uint32_t spill_depth, uint32_t spill_stride,
                                                               uint32_t* __restrict__ next_ray, uint32_t* __restrict__ overflow,
                                                               TraceCounters* counters) {
-    traverse_body<COUNT, true, true, XF_LDS, XF_MANY>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
+    traverse_body<COUNT, true, true, XF_LDS, XF_MANY, LEAF64>(sc, ray_o, ray_d, n, cand, hit0, hit1, spill, spill_depth, spill_stride, next_ray, overflow, counters);
 }
 
 // Continuation for rays with more than kCandMax candidate instances (a rarity: that many bounding volumes pierced
@@ -1988,7 +2033,10 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         else PT_LAUNCH(tlas_kernel<true>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         // (the counting form always runs as the six-workgroup kernel: its counters do not fit the seven-wave register budget)
-        if (sc.nodes4)
+        if (sc.nodes4 && sc.leaves64)
+            PT_LAUNCH((traverse_kernel<true, true, false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else if (sc.nodes4)
             PT_LAUNCH((traverse_kernel<true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
                                spill_depth, stride, next_ray, overflow, counters);
         else
@@ -2001,7 +2049,22 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
         else PT_LAUNCH(tlas_kernel<false>, g_all, b, 0, st, sc, rays.o, rays.d, n, cand, counters);
         if (between) (void)hipEventRecord(between, st);
         // (the forms with the last argument set read the instance transforms from LDS only: scenes whose transforms all fit there)
-        if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= kXformLds7)
+        if (PT_XF_LDS && sc.nodes4 && sc.leaves64 && sc.seven_waves && sc.n_instances <= kXformLds7)
+            PT_LAUNCH((traverse_kernel7<false, true, false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.nodes4 && sc.leaves64 && sc.seven_waves && sc.n_instances <= 2u * kXformLds7)
+            PT_LAUNCH((traverse_kernel7<false, true, true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (sc.nodes4 && sc.leaves64 && sc.seven_waves)
+            PT_LAUNCH((traverse_kernel7<false, false, false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
+                               stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.nodes4 && sc.leaves64 && sc.n_instances <= kXformLds)
+            PT_LAUNCH((traverse_kernel<false, true, true, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else if (sc.nodes4 && sc.leaves64)
+            PT_LAUNCH((traverse_kernel<false, true, false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill,
+                               spill_depth, stride, next_ray, overflow, counters);
+        else if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= kXformLds7)
             PT_LAUNCH((traverse_kernel7<false, true>), g_p, b, 0, st, sc, rays.o, rays.d, n, cand, hits.h0, hits.h1, spill, spill_depth,
                                stride, next_ray, overflow, counters);
         else if (PT_XF_LDS && sc.nodes4 && sc.seven_waves && sc.n_instances <= 2u * kXformLds7)

@@ -22,6 +22,7 @@ struct BuildOptions {
     bool linear_tlas = false;         // no tree over the instance bounds whatever their number
     uint32_t traverse_waves = 0;      // 0: by the size of the geometry; 6 or 7: that form of the four-wide kernel
     uint32_t leaf_vote = 0;           // 0: by scene size and program; 1..16
+    int leaf_records = 0;             // four-wide leaves as aligned 64-byte records: 0 by the size of the geometry, 1 always, -1 never
     uint32_t build_threads = 0;       // 0: up to 16
     int program_mode = PTGPU_PROGRAM_PBR;
     bool verbose = false;
@@ -34,6 +35,7 @@ struct BuiltScene {
     std::vector<ptd::NodeQ> nodes;
     std::vector<ptd::TriQ> tris;           // + two padding records (the first is the dummy leaf of unused wide slots)
     std::vector<ptd::Node4> nodes4;        // empty without four-wide nodes
+    std::vector<ptd::Leaf64> leaves64;     // four-wide trees' leaves as 64-byte records (then nodes4 refers to these), or empty
     std::vector<ptd::TlasNode> tlas;       // empty: every ray tests every instance bound
     std::vector<ptd::DevInstance> instances;
     std::vector<ptd::DevXform> xforms;
@@ -74,6 +76,11 @@ void build_instance_tree(const std::vector<ptd::DevInstance>& instances, std::ve
 bool collapse_to_wide(const std::vector<ptd::DevNode>& nodes, const std::vector<uint32_t>& binary_root, uint32_t dummy_leaf,
                       bool greedy, std::vector<ptd::Node4>& wide, std::vector<uint32_t>& mesh_root4, uint32_t* max_depth4,
                       std::string* err);
+// The leaves of the four-wide trees (runs of one or two 48-byte triangle records) as 64-byte records; the leaf references
+// of `wide` and `mesh_root4` are rewritten to record numbers.  `tris` = binary-order triangle records with leaf counts,
+// `n_real` of them real (the dummy leaf at tris[n_real] becomes a record of its own).
+void make_leaf_records(const std::vector<ptd::DevTri>& tris, uint32_t n_real, std::vector<ptd::Node4>& wide, std::vector<uint32_t>& mesh_root4,
+                       std::vector<ptd::Leaf64>& out);
 uint32_t number_top_nodes4(std::vector<ptd::Node4>& wide, std::vector<uint32_t>& mesh_root4, const std::vector<float>& mesh_weight,
                            uint32_t capacity);
 

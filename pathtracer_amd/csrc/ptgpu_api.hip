@@ -172,9 +172,10 @@ struct ptgpu_ctx {
     bool scene_loaded = false, camera_set = false;
     ptgpu_options options{};          // tuning (ptgpu_set_options); zero fields mean "the library's choice"
     bool has_nodes4 = false;          // the loaded scene carries four-wide nodes
+    bool has_leaves64 = false;        // ... whose leaves are 64-byte records
 
     // scene
-    DevBuf nodes, nodes4, tlas, tris, instances, xforms, objects, corners, texels, env, lut;
+    DevBuf nodes, nodes4, leaves64, tlas, tris, instances, xforms, objects, corners, texels, env, lut;
     ptd::SceneDev scene{};
     std::vector<ptgpu_bvh_info> bvh_info;
     std::vector<uint32_t> object_mesh;  // object -> mesh index (for hit dumps)
@@ -264,6 +265,8 @@ ptgpu_options options_from_environment() {
     if (is("PTGPU_WIDE_SPLITS", "reference")) o.flags |= PTGPU_OPT_REFERENCE_SPLITS;
     if (is("PTGPU_WIDE_COLLAPSE", "greedy")) o.flags |= PTGPU_OPT_GREEDY_COLLAPSE;
     if (is("PTGPU_TLAS", "linear")) o.flags |= PTGPU_OPT_LINEAR_TLAS;
+    if (is("PTGPU_LEAF_RECORDS", "1")) o.flags |= PTGPU_OPT_LEAF_RECORDS;
+    if (is("PTGPU_LEAF_RECORDS", "0")) o.flags |= PTGPU_OPT_NO_LEAF_RECORDS;
     const uint32_t verbose = number("PTGPU_VERBOSE", 1, 9);
     if (verbose >= 1) o.flags |= PTGPU_OPT_VERBOSE;
     if (verbose >= 2) o.flags |= PTGPU_OPT_VERBOSE_LAUNCHES;
@@ -719,7 +722,7 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
 int ptgpu_set_options(ptgpu_ctx* c, const ptgpu_options* o) {
     if (!c || !o) return PTGPU_E_INVALID;
     if (o->flags & ~(PTGPU_OPT_EXTEND_SIMPLE | PTGPU_OPT_REFERENCE_SPLITS | PTGPU_OPT_GREEDY_COLLAPSE | PTGPU_OPT_LINEAR_TLAS |
-                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES))
+                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES | PTGPU_OPT_LEAF_RECORDS | PTGPU_OPT_NO_LEAF_RECORDS))
         return c->fail(PTGPU_E_INVALID, "set_options: unknown flag bits 0x%x", o->flags);
     if ((o->chunk_rays && (o->chunk_rays < 1024 || o->chunk_rays > (1u << 28))) || o->pool_gib > 256 ||
         (o->traverse_waves && o->traverse_waves != 6 && o->traverse_waves != 7) || o->leaf_vote > 16 || o->build_threads > 64)
@@ -752,6 +755,7 @@ static void point_scene_at_buffers(ptgpu_ctx* c) {
     sc.env = c->env.as<float4>();
     sc.srgb_lut = c->lut.as<float>();
     sc.nodes4 = c->has_nodes4 ? c->nodes4.as<ptd::Node4>() : nullptr;
+    sc.leaves64 = (c->has_nodes4 && c->has_leaves64) ? c->leaves64.as<ptd::Leaf64>() : nullptr;
     sc.tlas = sc.n_tlas ? c->tlas.as<ptd::TlasNode>() : nullptr;
 }
 
@@ -770,6 +774,7 @@ static int upload_built_scene(ptgpu_ctx* c, const pth::BuiltScene& b, const ptgp
     if ((rc = upload(c, c->nodes, b.nodes.data(), b.nodes.size()))) return rc;
     if ((rc = upload(c, c->tris, b.tris.data(), b.tris.size()))) return rc;
     if (!b.nodes4.empty() && (rc = upload(c, c->nodes4, b.nodes4.data(), b.nodes4.size()))) return rc;
+    if (!b.leaves64.empty() && (rc = upload(c, c->leaves64, b.leaves64.data(), b.leaves64.size()))) return rc;
     if (!b.tlas.empty() && (rc = upload(c, c->tlas, b.tlas.data(), b.tlas.size()))) return rc;
     if ((rc = upload(c, c->instances, b.instances.data(), b.instances.size()))) return rc;
     if ((rc = upload(c, c->xforms, b.xforms.data(), b.xforms.size()))) return rc;
@@ -790,6 +795,7 @@ static int upload_built_scene(ptgpu_ctx* c, const pth::BuiltScene& b, const ptgp
     sc.env_w = env_w;
     sc.env_h = env_h;
     c->has_nodes4 = !b.nodes4.empty();
+    c->has_leaves64 = !b.leaves64.empty();
     point_scene_at_buffers(c);
     c->bvh_info = b.bvh_info;
     c->object_mesh = b.object_mesh;
@@ -815,6 +821,7 @@ int ptgpu_load_scene(ptgpu_ctx* c, const ptgpu_model* model, const ptgpu_envmap*
     bo.linear_tlas = (c->options.flags & PTGPU_OPT_LINEAR_TLAS) != 0;
     bo.traverse_waves = c->options.traverse_waves;
     bo.leaf_vote = c->options.leaf_vote;
+    bo.leaf_records = (c->options.flags & PTGPU_OPT_LEAF_RECORDS) ? 1 : ((c->options.flags & PTGPU_OPT_NO_LEAF_RECORDS) ? -1 : 0);
     bo.build_threads = c->options.build_threads;
     bo.program_mode = s.program_mode;
     bo.verbose = (c->options.flags & PTGPU_OPT_VERBOSE) != 0;
@@ -853,7 +860,7 @@ int ptgpu_load_scene_from(ptgpu_ctx* c, const ptgpu_ctx* src) {
     };
     ptgpu_ctx* d = c;
     const std::pair<DevBuf*, const DevBuf*> pairs[] = {
-        {&d->nodes, &src->nodes}, {&d->tris, &src->tris}, {&d->nodes4, &src->nodes4}, {&d->tlas, &src->tlas},
+        {&d->nodes, &src->nodes}, {&d->tris, &src->tris}, {&d->nodes4, &src->nodes4}, {&d->leaves64, &src->leaves64}, {&d->tlas, &src->tlas},
         {&d->instances, &src->instances}, {&d->xforms, &src->xforms}, {&d->objects, &src->objects}, {&d->corners, &src->corners},
         {&d->texels, &src->texels}, {&d->env, &src->env}, {&d->lut, &src->lut}, {&d->d_object_mesh, &src->d_object_mesh}};
     for (const auto& pr : pairs) {
@@ -862,6 +869,7 @@ int ptgpu_load_scene_from(ptgpu_ctx* c, const ptgpu_ctx* src) {
     }
     c->scene = src->scene;  // the scalars; the pointers are set to this context's buffers next
     c->has_nodes4 = src->has_nodes4;
+    c->has_leaves64 = src->has_leaves64;
     point_scene_at_buffers(c);
     c->bvh_info = src->bvh_info;
     c->object_mesh = src->object_mesh;

@@ -437,6 +437,50 @@ def test_axis_parallel_rays_over_wide_nodes(materials):
         assert exact.mean() >= (0.9999 if wide else 1.0), (wide, int((~exact).sum()))
 
 
+@pytest.mark.parametrize("scene", ["materials", "mesh", "soup"])
+def test_leaf_records_change_no_result(materials, scene):
+    """Large scenes store the leaves of their four-wide trees as one aligned 64-byte record each (the one or two triangles as
+    their three or four distinct corners; the kernel forms the edge vectors itself) instead of 48-byte triangle records.
+    Same tree, same triangles, same arithmetic: closest-hit records, any-hit records (which triangle included) and ray counts
+    are equal to the bit with the records forced on and off, and the closest hits are the oracle's."""
+    rng = np.random.default_rng(17)
+    if scene == "materials":
+        model, env = materials
+    elif scene == "mesh":
+        model, env = scenes.stress_mesh(300_000), None
+    else:   # unstructured triangles: most leaves' two triangles share no edge and take two records
+        from pathtracer_amd.model import Camera, ModelBuilder
+        n_t = 4000
+        c = rng.uniform(-2, 2, (n_t, 1, 3))
+        pos = (c + rng.uniform(-0.15, 0.15, (n_t, 3, 3))).astype(np.float32).reshape(-1, 3)
+        mb = ModelBuilder()
+        mb.add_object(mb.add_mesh(pos, np.tile([[0, 0, 1]], (len(pos), 1)), np.arange(len(pos)), material=mb.add_material(double_sided=True)))
+        mb.add_camera(Camera(position=(0, 0, 6), direction=(0, 0, -1), up=(0, 1, 0), yfov=0.8, znear=0.1, zfar=100.0))
+        model, env = mb.build(), None
+    lo, hi = model.vertices["position"].min(axis=0), model.vertices["position"].max(axis=0)
+    n = 40000
+    org = rng.uniform(lo - 1, hi + 1, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    d = tgt - org
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    any_flags = np.ones(n, np.uint8)
+    w, h = 160, 96
+    st = H.settings(program=2, spp=2, bounces=4, wide=True)
+    results = []
+    for flag in (abi.OPT_NO_LEAF_RECORDS, abi.OPT_LEAF_RECORDS):
+        g = H.make_gpu(model, env, st, w, h, flags=flag)
+        img, s = H.gpu_render(g, w, h)
+        _, sc = g.render_counted(w, h)
+        results.append((g.intersect_rays(org, d), g.intersect_rays(org, d, any_flags), int(s.rays), img, int(sc.triangles_tested), int(sc.nodes_visited)))
+    (c0, a0, r0, i0, t0, n0), (c1, a1, r1, i1, t1, n1) = results
+    assert c0.tobytes() == c1.tobytes() and a0.tobytes() == a1.tobytes() and r0 == r1 and (t0, n0) == (t1, n1)
+    assert c0["hit"].sum() > 1000
+    assert np.abs(i0 - i1).max() <= 2e-5 * max(1.0, float(np.abs(i0).max()))
+    ref = H.make_oracle(model, env, H.settings(program=2, spp=2, bounces=4), w, h).intersect_rays(org, d)
+    exact, _ = H.hits_equal(ref, c1)
+    assert exact.mean() >= 0.9999
+
+
 @pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
 def test_random_soups_both_node_layouts(seed, offset, flat):
     """Unstructured triangle soups under random affine transforms, also far from the object-space origin (box planes and

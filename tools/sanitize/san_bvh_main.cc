@@ -121,7 +121,13 @@ void make_model(TestModel& t, const std::vector<uint32_t>& mesh_sizes, uint32_t 
 // unused slots are inverted and name the dummy leaf; the first n_top4 nodes are reachable like the others.
 uint64_t check_wide(const pth::BuiltScene& b) {
     const uint32_t n_tris = static_cast<uint32_t>(b.tris.size()) - 2u;
-    const uint32_t dummy = PT_LEAF_BIT | n_tris;
+    uint32_t dummy = PT_LEAF_BIT | n_tris;
+    if (!b.leaves64.empty()) {  // the dummy leaf is the record whose corners are all zero and that names triangle 0 once more
+        dummy = PT_NO_NODE;
+        for (const ptd::Node4& nd : b.nodes4)
+            for (int k = 0; k < 4; ++k)
+                if ((nd.ref[k] & PT_LEAF_BIT) && ((nd.qlo[0] >> (8 * k)) & 0xffu) == 255u && ((nd.qhi[0] >> (8 * k)) & 0xffu) == 0u) dummy = nd.ref[k];
+    }
     std::vector<int> seen(n_tris, 0);
     std::vector<char> root_done(b.nodes4.size(), 0);
     uint64_t visited = 0;
@@ -139,6 +145,41 @@ uint64_t check_wide(const pth::BuiltScene& b) {
         while (!todo.empty()) {
             const Item it = todo.back();
             todo.pop_back();
+            if ((it.ref & PT_LEAF_BIT) && !b.leaves64.empty()) {
+                // leaf records: every triangle of the leaf, rebuilt from the record's corners and selectors, equals a
+                // 48-byte record of the same leaf (same p1, same edges, same index), in the same order
+                uint32_t rec = it.ref & ~PT_LEAF_BIT;
+                check(rec < b.leaves64.size(), "leaf record in range");
+                for (;; ++rec) {
+                    check(rec < b.leaves64.size(), "a continued leaf ends inside the record array");
+                    const ptd::Leaf64& r = b.leaves64[rec];
+                    const int n_in = (r.info & 1u) ? 2 : 1;
+                    for (int which = 0; which < n_in; ++which) {
+                        const uint32_t sel[3] = {which ? (r.info >> 8) & 3u : 0u, which ? (r.info >> 10) & 3u : 1u, which ? (r.info >> 12) & 3u : 2u};
+                        const uint32_t index = which ? r.index1 : r.index0;
+                        // find the 48-byte record with this index among the real triangles (indices are unique per mesh; the
+                        // leaf's box check below does the rest)
+                        bool found = false;
+                        for (uint32_t t = 0; t < n_tris && !found; ++t) {
+                            const ptd::TriQ& q = b.tris[t];
+                            if (q.index != index) continue;
+                            bool equal = true;
+                            for (int a = 0; a < 3; ++a) {
+                                const float p1 = r.v[sel[0]][a], e1 = r.v[sel[1]][a] - p1, e2 = r.v[sel[2]][a] - p1;
+                                equal = equal && std::memcmp(&p1, &q.p1[a], 4) == 0 && std::memcmp(&e1, &q.e1[a], 4) == 0 && std::memcmp(&e2, &q.e2[a], 4) == 0;
+                            }
+                            if (!equal) continue;
+                            found = true;
+                            ++seen[t];
+                        }
+                        check(found, "a leaf record's triangle is one of the scene's triangles, bit for bit");
+                        for (int k = 0; k < 3; ++k)
+                            for (int a = 0; a < 3; ++a) check(r.v[sel[k]][a] >= it.lo[a] && r.v[sel[k]][a] <= it.hi[a], "corner inside its leaf's decoded box");
+                    }
+                    if (!(r.info & 2u)) break;
+                }
+                continue;
+            }
             if (it.ref & PT_LEAF_BIT) {
                 const uint32_t first = it.ref & ~PT_LEAF_BIT;
                 check(first < n_tris, "wide leaf starts at a real triangle");
@@ -312,12 +353,15 @@ int main() {
     }
     // ---- (2) the whole scene build, four-wide nodes ----
     uint64_t wide_nodes = 0;
+    for (int leaf_records : {-1, 1})
     for (bool greedy : {false, true})
         for (bool reference_splits : {false, true})
             for (float offset : {0.0f, 5000.0f})
                 for (uint32_t n_objects : {1u, 5u, 130u}) {  // 130 > kTlasLinearMax: with the tree over the instance bounds
+                    if (leaf_records > 0 && (greedy || n_objects == 130u)) continue;
                     TestModel tm;
-                    make_model(tm, {1u, 2u, 3u, 5u, 300u, 20000u}, n_objects, offset);
+                    if (leaf_records > 0) make_model(tm, {1u, 2u, 3u, 5u, 300u, 1500u}, n_objects, offset);
+                    else make_model(tm, {1u, 2u, 3u, 5u, 300u, 20000u}, n_objects, offset);
                     std::string err;
                     check(pth::validate_model(tm.model, &err), "a finite model validates");
                     pth::BuildOptions bo;
@@ -325,6 +369,7 @@ int main() {
                     bo.greedy_collapse = greedy;
                     bo.reference_splits = reference_splits;
                     bo.build_threads = 2;
+                    bo.leaf_records = leaf_records;
                     pth::BuiltScene built;
                     int code = 0;
                     if (!pth::build_scene(tm.model, bo, built, &err, &code)) {
@@ -332,6 +377,7 @@ int main() {
                         return 1;
                     }
                     check(!built.nodes4.empty() && built.tris.size() >= 2, "four-wide nodes were made");
+                    check((leaf_records > 0) == !built.leaves64.empty(), "leaf records exactly when asked for");
                     check(built.n_top4 <= static_cast<uint32_t>(ptd::kTopNodes4) && built.n_top4 <= built.nodes4.size(), "top-node count within the LDS table");
                     check(built.n_top <= static_cast<uint32_t>(ptd::kTopNodes), "binary top-node count within the LDS table");
                     check((n_objects > ptd::kTlasLinearMax) == !built.tlas.empty(), "instance tree exactly when there are many instances");
