@@ -129,6 +129,153 @@ def cpu_baseline(model, env, cfg, seconds_target: float = 8.0):
     return out
 
 
+PROFILE_TAG = "r03"          # profiles/<tag>_hbm_traffic.json, profiles/<tag>_counters_<name>.txt
+COUNTER_FILES = {"readme_pbr": "readme", "ao_1080p": "ao", "raycast_640": "raycast", "stress_4k": "stress", "material_4k": "material"}
+# Ceilings of the paths that bind this kernel, measured on this part with tools/micro/gather_bench.hip: what the vector L1s
+# sustain for divergent 64-byte records read as four 16-byte loads (GB/s over all CUs), and what the memory fabric
+# delivers for dependent random 64-byte sectors that miss the L2.
+L1_GATHER_CEILING_GBPS = 14200.0
+FABRIC_SECTOR_CEILING_GBPS = 3700.0
+HBM_PEAK_GBPS = 8000.0
+
+
+def roofline(args, cfg, model, r, settings, st, tot, w, h):
+    """The `roofline` object of the line, for the dominant kernel (the persistent traversal kernel).
+
+    Algorithmic bytes: per ray the kernel reads origin + direction (32 B) and its candidate list (8 B per entered instance
+    plus the end word), a 128 B transform per entered instance, 64 B per visited node (binary: two children's boxes;
+    four-wide: four children's quantised boxes) and 48 B per tested triangle — or 64 B per leaf record where the scene's
+    leaves are stored that way — and writes a 20 B hit record; all counted on the same scene and camera at reduced spp by
+    the counting form of the kernel.  Measured bytes: FETCH_SIZE + WRITE_SIZE of the committed counter passes of this
+    configuration (bytes that crossed the L2 <-> fabric boundary), per ray, scaled to the rays of a launch here.
+    Which resource binds is read off the committed utilisation counters of the configuration: the headline `frac` is
+    against THAT resource's measured ceiling; the fraction of the HBM peak is kept beside it under `hbm`."""
+    import re
+    from pathtracer_amd.renderer import AccelerationStructureType, RayProgramMode, RenderSettings
+    count_settings = RenderSettings(min(cfg["spp"], 8), cfg["bounces"], cfg["newrays"], 8, 0.0,
+                                    RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
+                                    singlePath=bool(cfg.get("single")), wideNodes=not args.binary_nodes)
+    r.set_render_settings(count_settings)
+    _, cst = r.render_counted(w, h)
+    r.set_render_settings(settings)
+    V = cst.nodes_visited / cst.rays
+    T = cst.triangles_tested / cst.rays
+    LR = getattr(cst, "leaf_records_read", 0) / cst.rays
+    I = cst.instances_tested / cst.rays
+    E = cst.instances_entered / cst.rays
+    leaf_bytes = LR * 64 if LR > 0 else T * 48
+    bytes_per_ray = V * 64 + leaf_bytes + E * 128 + (E + 1) * 8 + 32 + 20
+    tlas_bytes_per_ray = I * 64 + 32 + (E + 1) * 8
+    launches = max(tot["extend_launches"], 1)
+    avg_launch_s = tot["traverse_ms"] / 1e3 / launches
+    rays_per_launch = tot["rays"] / launches
+    algorithmic = bytes_per_ray * rays_per_launch
+    lds_visits = getattr(cst, "nodes_from_lds", 0) / max(cst.rays, 1)
+    l1_bytes = algorithmic - lds_visits * 64 * rays_per_launch
+    l1_gbps = l1_bytes / avg_launch_s / 1e9
+
+    # ---- measured fabric traffic: the committed FETCH_SIZE / WRITE_SIZE passes of this configuration ----
+    measured = source = kernel_key = None
+    tpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_hbm_traffic.json")
+    key = f"{args.config}/{'binary' if args.binary_nodes else 'wide'}"
+    scene_text = f"{model.instanced_triangles()} triangles, {len(model.objects)} objects"
+    if os.path.exists(tpath):
+        entry = json.load(open(tpath)).get("configs", {}).get(key) or {}
+        # the traversal kernel of the profile: the non-counting traverse_kernel* entry with the largest share of the GPU time
+        names = [k for k in entry.get("kernels", {}) if k.startswith("traverse_kernel") and "<false" in k and "fetch_bytes_per_ray" in entry["kernels"][k]]
+        if names and entry.get("scene") == scene_text and entry.get("bounces") == cfg["bounces"] and entry.get("resolution") == [w, h]:
+            kernel_key = max(names, key=lambda k: entry["kernels"][k].get("share_of_gpu_time_pct", 0.0))
+            k = entry["kernels"][kernel_key]
+            measured = (k["fetch_bytes_per_ray"] + k["write_bytes_per_ray"]) * rays_per_launch
+            source = (f"profiles/{PROFILE_TAG}_hbm_traffic.json[{key}][{kernel_key}] ({entry.get('profile', '')}): "
+                      f"{k['fetch_bytes_per_ray']:.1f} B fetched + {k['write_bytes_per_ray']:.1f} B written per ray")
+    fabric_gbps = (measured / avg_launch_s / 1e9) if measured else None
+
+    # ---- utilisation of the kernel's units: the committed counter passes of this configuration ----
+    util = None
+    cname = COUNTER_FILES.get(args.config)
+    cpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_counters_{cname}.txt") if cname and not args.binary_nodes else ""
+    if cpath and os.path.isfile(cpath):
+        text = open(cpath).read()
+        blocks = re.findall(r"^== (traverse_kernel[^\n]*<false[^\n]*) ==\n((?:  [^\n]*\n)+)", text, flags=re.M)
+        if blocks:
+            def grab(block, pattern):
+                m = re.search(pattern, block)
+                return float(m.group(1)) if m else None
+            # (the traversal kernel with the most busy clocks, should the pass hold more than one form)
+            name, block = max(blocks, key=lambda nb: grab(nb[1], r"busy clocks per XCD\s+([0-9]+)") or 0.0)
+            util = {"kernel": name,
+                    "valu_utilisation": grab(block, r"VALU utilisation \([^)]*\)\s+([0-9.]+)"),
+                    "waves_per_simd": grab(block, r"mean waves per SIMD \([^)]*\)\s+([0-9.]+)"),
+                    "wave_time_waiting": grab(block, r"wave time: waiting ([0-9.]+)"),
+                    "wave_time_ready_not_issued": grab(block, r"issue-stalled ([0-9.]+)"),
+                    "address_unit_busy": grab(block, r"TA busy ([0-9.]+)"),
+                    "l2_hit_rate": grab(block, r"L2: hit rate ([0-9.]+)"),
+                    "source": os.path.relpath(cpath, ROOT) + " (rocprofv3 --pmc passes of this configuration at a reduced sample count)"}
+
+    # ---- which resource binds ----
+    hbm = {"achieved": round(fabric_gbps, 2) if fabric_gbps else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(fabric_gbps / HBM_PEAK_GBPS, 5) if fabric_gbps else None,
+           "note": "measured fabric bytes (L2 misses: served by the Infinity Cache or HBM) / kernel time against the HBM peak; "
+                   "an upper bound of the HBM share"}
+    if rays_per_launch < 2e6 and avg_launch_s < 1e-3:
+        bound, achieved, peak = "launch-latency", l1_gbps, L1_GATHER_CEILING_GBPS
+        binding = (f"a launch of {rays_per_launch:.0f} rays lasts {avg_launch_s * 1e6:.0f} us: the frame is a handful of kernel launches and a "
+                   f"read-back, no unit is busy; the figure is against the L1 gather ceiling for completeness")
+    elif util and fabric_gbps and (util["l2_hit_rate"] or 1.0) < 0.45 and fabric_gbps >= 0.75 * FABRIC_SECTOR_CEILING_GBPS:
+        bound, achieved, peak = "fabric-sectors", fabric_gbps, FABRIC_SECTOR_CEILING_GBPS
+        binding = (f"the scene is beyond the caches (L2 hit rate {util['l2_hit_rate']:.2f}): the fabric delivers {fabric_gbps:.0f} GB/s of random 64-byte "
+                   f"sectors against the {FABRIC_SECTOR_CEILING_GBPS:.0f} GB/s a dependent random-sector gather reaches on this part "
+                   f"(tools/micro/gather_bench.hip); address unit busy {util['address_unit_busy']:.2f}, vector ALU {util['valu_utilisation']:.2f}; "
+                   f"what moves it is sectors per ray")
+    elif util:
+        bound, achieved, peak = "l1-gather+issue", l1_gbps, L1_GATHER_CEILING_GBPS
+        binding = (f"cache-resident (L2 hit rate {util['l2_hit_rate']:.2f}): a dependent chain of gathers through the vector L1 — address unit busy "
+                   f"{util['address_unit_busy']:.2f} of the time, vector ALU {util['valu_utilisation']:.2f} at {util['waves_per_simd']:.1f} waves per SIMD, "
+                   f"{util['wave_time_waiting']:.2f} of wave time waiting and {util['wave_time_ready_not_issued']:.2f} ready but not issued; "
+                   f"not memory bandwidth (fabric at {hbm['frac'] if hbm['frac'] is not None else float('nan'):.2f} of the HBM peak)")
+    else:
+        bound, achieved, peak = "l1-gather+issue", l1_gbps, L1_GATHER_CEILING_GBPS
+        binding = "no utilisation counter pass is committed for this configuration and node layout: the L1 gather path is assumed"
+    return {
+        "kernel": kernel_key or (util or {}).get("kernel") or "traverse_kernel*",
+        "bound": bound,
+        "achieved": round(achieved, 2),
+        "peak": peak,
+        "unit": "GB/s",
+        "frac": round(achieved / peak, 5),
+        "traffic": round(measured) if measured else None,
+        "traffic_source": source,
+        "binding": binding,
+        "hbm": hbm,
+        "utilisation": util,
+        "algorithmic_GBps": round(algorithmic / avg_launch_s / 1e9, 2),
+        "algorithmic_frac_of_hbm_peak": round(algorithmic / avg_launch_s / 1e9 / HBM_PEAK_GBPS, 5),
+        "algorithmic_bytes_per_launch": round(algorithmic),
+        "l1_side": {"GBps": round(l1_gbps, 2), "ceiling_GBps": L1_GATHER_CEILING_GBPS, "frac": round(l1_gbps / L1_GATHER_CEILING_GBPS, 4),
+                    "note": "algorithmic bytes minus the node visits served from the LDS node cache, against the rate the vector L1s "
+                            "sustain for divergent 64-byte records read as four 16-byte loads back to back (tools/micro/gather_bench.hip)"},
+        "note": "bound / frac: the resource the committed counters show to bind, against its measured ceiling; hbm.frac = measured fabric "
+                "bytes / kernel time / 8 TB/s; algorithmic_* counts every visit as a fetch whichever cache served it (work done, not a bound)",
+        "bytes_per_ray": round(bytes_per_ray, 1),
+        "per_ray": {"nodes_64B": round(V, 3), "nodes_served_from_lds": round(lds_visits, 3), "triangles_tested": round(T, 3),
+                    "leaf_records_64B": round(LR, 3) if LR > 0 else None, "triangle_records_48B": round(T, 3) if LR == 0 else None,
+                    "instances_entered_128B_plus_8B": round(E, 3), "ray_read_B": 32, "hit_write_B": 20},
+        "rays_per_launch": round(rays_per_launch),
+        "avg_launch_ms": round(tot["traverse_ms"] / launches, 4),
+        "launches_per_step": tot["extend_launches"] // max(args.steps, 1),
+        "traverse_workgroups_per_cu": getattr(st, "traverse_workgroups_per_cu", 0),
+        "traverse_share_of_step": round(tot["traverse_ms"] / (tot["elapsed"] * 1e3), 4),
+        "instance_pass": {"kernel": "tlas_kernel<false>", "bytes_per_ray": round(tlas_bytes_per_ray, 1),
+                          "instance_bounds_64B": round(I, 3),
+                          "avg_launch_ms": round((tot["extend_ms"] - tot["traverse_ms"]) / launches, 4),
+                          "share_of_step": round((tot["extend_ms"] - tot["traverse_ms"]) / (tot["elapsed"] * 1e3), 4)},
+        "extend_share_of_step": round(tot["extend_ms"] / (tot["elapsed"] * 1e3), 4),
+        "shade_share_of_step": round(tot["shade_ms"] / (tot["elapsed"] * 1e3), 4),
+        "extend_mrays_per_s": round(tot["rays"] / (tot["extend_ms"] / 1e3) / 1e6, 2),
+    }
+
+
 def launch_ranks(n: int, argv: list[str]) -> int:
     """Start `n` ranks of this script (one per GPU) and wait for them.  The launcher itself never imports torch and never
     touches a GPU: the children are fresh processes, started before anything here could have initialised a device.
@@ -366,122 +513,9 @@ def main() -> None:
             },
         }
         if not args.no_roofline:  # rank 0's own launches (every rank holds the same scene)
-            # Algorithmic bytes of the traversal kernel (the dominant one), counted on the same scene and camera at
-            # reduced spp: per ray it reads origin + direction (32 B) and its candidate list (8 B per entered instance
-            # plus the terminator), a 128 B transform per entered instance, 64 B per visited node (binary: two children's
-            # boxes; four-wide: four children's quantised boxes) and 48 B per tested triangle, and writes a 20 B hit record.  The instance pass before it (tlas_kernel) reads 32 B + 64 B per
-            # tested instance bound and writes the candidate list; it is timed inside extend_ms but not in traverse_ms.
-            count_settings = RenderSettings(min(cfg["spp"], 8), cfg["bounces"], cfg["newrays"], 8, 0.0,
-                                            RayProgramMode(cfg["program"]), AccelerationStructureType.BVH, seed=1234,
-                                            singlePath=bool(cfg.get("single")), wideNodes=not args.binary_nodes)
-            r.set_render_settings(count_settings)
-            _, cst = r.render_counted(w, h)
-            r.set_render_settings(settings)
-            V = cst.nodes_visited / cst.rays
-            T = cst.triangles_tested / cst.rays
-            I = cst.instances_tested / cst.rays
-            E = cst.instances_entered / cst.rays
-            bytes_per_ray = V * 64 + T * 48 + E * 128 + (E + 1) * 8 + 32 + 20
-            tlas_bytes_per_ray = I * 64 + 32 + (E + 1) * 8
-            traverse_s = traverse_ms / 1e3
-            # the kernel's name as the profiler prints it: <counting, four-wide nodes, every instance transform in LDS>
-            seven = not args.binary_nodes and getattr(st, "traverse_workgroups_per_cu", 6) == 7  # the form for scenes the caches hold
-            xf_lds = "true" if len(model.objects) <= (24 if seven else 16) else "false"
-            if seven:  # (its third argument: the form with 24 instead of 12 transforms in LDS)
-                xf_many = "true" if 12 < len(model.objects) <= 24 else "false"
-                kernel_name, legacy_name = f"traverse_kernel7<false, {xf_lds}, {xf_many}>", "traverse_kernel7<false>"
-            elif args.binary_nodes:
-                kernel_name, legacy_name = f"traverse_kernel<false, false, {xf_lds}>", "traverse_kernel<false, false>"
-            else:
-                kernel_name, legacy_name = f"traverse_kernel<false, true, {xf_lds}>", "traverse_kernel<false, true>"
-            launches = max(extend_launches, 1)
-            avg_launch_s = traverse_s / launches
-            rays_per_launch = rays / launches
-            algorithmic = bytes_per_ray * rays_per_launch
-            # Bytes that crossed the L2 <-> fabric boundary (Infinity Cache or HBM behind it), per ray, from the committed
-            # counter passes of this configuration (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in a run of its own over
-            # this same command: tools/profile_bench.sh); scaled to the rays of one launch here.  FETCH_SIZE is taken as
-            # reported: the kernel reads random 64-byte sectors, for which the counter is exact
-            # (tools/micro/calibrate_fetch.sh); the doubling rule applies to streaming 128-byte requests only.
-            measured = None
-            source = None
-            tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-            key = f"{args.config}/{'binary' if args.binary_nodes else 'wide'}"
-            if os.path.exists(tpath):
-                entry = json.load(open(tpath)).get("configs", {}).get(key)
-                kernels = (entry or {}).get("kernels", {})
-                k = kernels.get(kernel_name) or kernels.get(legacy_name)  # (profiles taken before the kernels had the last argument)
-                same_scene = entry and entry.get("scene") == f"{model.instanced_triangles()} triangles, {len(model.objects)} objects"
-                if k and same_scene and entry.get("bounces") == cfg["bounces"] and entry.get("resolution") == [w, h]:
-                    measured = (k["fetch_bytes_per_ray"] + k["write_bytes_per_ray"]) * rays_per_launch
-                    source = f"profiles/r02_hbm_traffic.json[{key}] ({entry.get('profile', '')}): " \
-                             f"{k['fetch_bytes_per_ray']:.1f} B fetched + {k['write_bytes_per_ray']:.1f} B written per ray"
-            lds_visits = getattr(cst, "nodes_from_lds", 0) / max(cst.rays, 1)
-            l1_bytes = algorithmic - lds_visits * 64 * rays_per_launch
-            # `achieved` / `frac`: what the memory system behind the L2 delivered to the dominant kernel per second, against the
-            # HBM peak.  It cannot exceed 1.  The algorithmic figure (every node / triangle visit counted as a fetch,
-            # whichever cache served it) is kept beside it: it measures the work done, not a bound.
-            achieved = (measured / avg_launch_s / 1e9) if measured else None
-            # The secondary bounds of the same kernel (vector ALU, L1 address unit), from the committed utilisation counter
-            # passes of this configuration (tools/counters_report.sh); null for configurations without such a pass.
-            secondary = None
-            cpath = os.path.join(ROOT, "profiles", {"readme_pbr": "r02_counters_readme.txt", "stress_4k": "r02_counters_stress.txt"}.get(args.config, ""))
-            if os.path.isfile(cpath):
-                import re
-                text = open(cpath).read()
-                at = text.find(f"== {kernel_name} ==")
-                if at >= 0:
-                    block = text[at:text.find("\n== ", at + 4) if text.find("\n== ", at + 4) > 0 else len(text)]
-                    def grab(pattern):
-                        m = re.search(pattern, block)
-                        return float(m.group(1)) if m else None
-                    secondary = {"valu_utilisation": grab(r"VALU utilisation \([^)]*\)\s+([0-9.]+)"),
-                                 "waves_per_simd": grab(r"mean waves per SIMD \([^)]*\)\s+([0-9.]+)"),
-                                 "wave_time_waiting": grab(r"wave time: waiting ([0-9.]+)"),
-                                 "address_unit_busy": grab(r"TA busy ([0-9.]+)"),
-                                 "l2_hit_rate": grab(r"L2: hit rate ([0-9.]+)"),
-                                 "source": os.path.relpath(cpath, ROOT) + " (rocprofv3 --pmc passes of the same configuration at a reduced sample count)"}
-            line["roofline"] = {
-                "kernel": kernel_name,
-                "bound": "hbm",
-                "achieved": round(achieved, 2) if achieved else None,
-                "peak": 8000.0,
-                "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5) if achieved else None,
-                "traffic": round(measured) if measured else None,
-                "traffic_source": source,
-                "algorithmic_GBps": round(algorithmic / avg_launch_s / 1e9, 2),
-                "algorithmic_frac_of_peak": round(algorithmic / avg_launch_s / 1e9 / 8000.0, 5),
-                "algorithmic_bytes_per_launch": round(algorithmic),
-                "l1_side": {"GBps": round(l1_bytes / avg_launch_s / 1e9, 2), "ceiling_GBps": 14200.0,
-                            "frac": round(l1_bytes / avg_launch_s / 1e9 / 14200.0, 4),
-                            "note": "algorithmic bytes minus the node visits served from the LDS node cache, against the rate the "
-                                    "vector L1s sustain for divergent 64-byte records read as four 16-byte loads back to back "
-                                    "(tools/micro/gather_bench.hip)"},
-                "binding": "not HBM bandwidth.  Cache-resident scenes (readme, AO, material): instruction issue and the L1 address unit "
-                           "on a dependent chain of ~17 fetches per ray (vector pipe 58 % busy at 6.7 waves per SIMD, 27 % of wave time "
-                           "ready but not issued, address unit 89 % busy; +25 % node loads cost +3 %, -10 % vector instructions gave "
-                           "-3.8 %, transforms read from LDS instead of through flat loads -1.5 %).  The 10 M-triangle stress scene: "
-                           "the L1 address unit (TA 97 % busy) with the fabric at ~0.95 of the measured random-64-byte-sector rate "
-                           "(profiles/r02_counters_readme.txt, profiles/r02_counters_stress.txt, DESIGN.md section 3)",
-                "secondary": secondary,
-                "note": "frac = measured fabric bytes (FETCH_SIZE + WRITE_SIZE: L2 misses, served by the Infinity Cache or HBM) / "
-                        "kernel time / 8 TB/s; algorithmic_* counts every visit as a fetch and may exceed the peak on "
-                        "cache-resident scenes",
-                "bytes_per_ray": round(bytes_per_ray, 1),
-                "per_ray": {"nodes_64B": round(V, 3), "nodes_served_from_lds": round(lds_visits, 3), "triangles_48B": round(T, 3),
-                            "instances_entered_128B_plus_8B": round(E, 3), "ray_read_B": 32, "hit_write_B": 20},
-                "rays_per_launch": round(rays_per_launch),
-                "avg_launch_ms": round(traverse_ms / launches, 4),
-                "launches_per_step": extend_launches // max(args.steps, 1),
-                "traverse_share_of_step": round(traverse_ms / (elapsed * 1e3), 4),
-                "instance_pass": {"kernel": "tlas_kernel<false>", "bytes_per_ray": round(tlas_bytes_per_ray, 1),
-                                  "instance_bounds_64B": round(I, 3),
-                                  "avg_launch_ms": round((extend_ms - traverse_ms) / launches, 4)},
-                "extend_share_of_step": round(extend_ms / (elapsed * 1e3), 4),
-                "shade_share_of_step": round(shade_ms / (elapsed * 1e3), 4),
-                "extend_mrays_per_s": round(rays / (extend_ms / 1e3) / 1e6, 2),
-            }
+            line["roofline"] = roofline(args, cfg, model, r, settings, st, dict(rays=rays, elapsed=elapsed, extend_ms=extend_ms,
+                                                                            traverse_ms=traverse_ms, shade_ms=shade_ms,
+                                                                            extend_launches=extend_launches), w, h)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, env, cfg)
         print(json.dumps(line), flush=True)

@@ -225,6 +225,7 @@ typedef struct ptgpu_stats {
     uint32_t traverse_workgroups_per_cu; /* form of the traversal kernel the loaded scene runs with: 6, or 7 (four-wide nodes
                                             over a scene the caches hold); 0 with PTGPU_EXTEND=simple */
     uint32_t reserved0;
+    uint64_t leaf_records_read; /* ptgpu_render_counted, scenes whose four-wide leaves are 64-byte records: records fetched (0 otherwise) */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

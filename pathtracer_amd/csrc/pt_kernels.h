@@ -91,6 +91,7 @@ struct TraceCounters {   // filled by the counting variant of extend
     // scheduler census of the persistent kernel: [phase 0 refill, 1 next, 2 inner, 3 leaf][0 executions, 1 steps,
     // 2..5 lanes idle / waiting for next / holding a node / holding a leaf, summed over the steps]
     unsigned long long census[4][6];
+    unsigned long long leaf_records;          // 64-byte leaf records fetched (scenes that have them)
 };
 
 // slots_in_batch == 0: camera samples [first, first + n) of the linear index (sample_slot * n_tiles + tile) * 64 + lane.

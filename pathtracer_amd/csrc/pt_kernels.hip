@@ -107,6 +107,7 @@ struct TraceCount {
     uint32_t nodes, tris, inst_tested, inst_entered;
     uint32_t wave_inner, wave_tri;  // loop iterations executed by the wavefront (counted by one lane per iteration)
     uint32_t census[4][6];
+    uint32_t leaf_records;
 };
 __device__ __forceinline__ bool first_active_lane() {
     const unsigned long long m = __ballot(1);
@@ -1038,7 +1039,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
                 if (WIDE && LEAF64 && is_leaf(cur)) {
                     // One aligned 64-byte record a step: the leaf's one or two triangles as their distinct corners.  The edges
                     // p2 - p1 and p3 - p1 are formed here, by the same two subtractions the 48-byte records were made with.
-                    if (COUNT) { ++cnt.tris; if (first_active_lane()) ++cnt.wave_tri; }
+                    if (COUNT) { ++cnt.tris; ++cnt.leaf_records; if (first_active_lane()) ++cnt.wave_tri; }
                     PT_PRIO_UP;
                     const float4* lp = reinterpret_cast<const float4*>(sc.leaves64 + (cur & ~PT_LEAF_BIT));
                     const float4 a = lp[0], b = lp[1], c = lp[2], m = lp[3];
@@ -1156,6 +1157,7 @@ __device__ __forceinline__ void traverse_body(const SceneDev& sc, const float4* 
         atomicAdd(&counters->wave_inner, static_cast<unsigned long long>(cnt.wave_inner));
         atomicAdd(&counters->wave_tri, static_cast<unsigned long long>(cnt.wave_tri));
         atomicAdd(&counters->census[1][0], static_cast<unsigned long long>(cnt.inst_tested));
+        atomicAdd(&counters->leaf_records, static_cast<unsigned long long>(cnt.leaf_records));
         if (lane == 0)
             for (int ph = 0; ph < 4; ++ph)
                 for (int k = 0; k < 6; ++k) atomicAdd(&counters->census[ph][k], static_cast<unsigned long long>(cnt.census[ph][k]));

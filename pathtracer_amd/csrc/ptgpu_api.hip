@@ -597,6 +597,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         out.wave_inner_iterations = tc.wave_inner;
         out.wave_triangle_iterations = tc.wave_tri;
         out.nodes_from_lds = tc.census[1][0];
+        out.leaf_records_read = tc.leaf_records;
         if (c->options.flags & PTGPU_OPT_VERBOSE) {
             std::fprintf(stderr, "[ptgpu] node visits served from LDS: %llu of %llu; rays that touch no instance: %llu\n", tc.census[1][0], tc.nodes,
                          tc.census[1][1]);
