@@ -321,9 +321,11 @@ int ptgpu_render_hits(ptgpu_ctx* ctx, int width, int height, uint32_t sample, pt
 int ptgpu_intersect_rays(ptgpu_ctx* ctx, uint64_t n, const float* origins, const float* directions,
                          const uint8_t* any_hit, ptgpu_hit* out);
 
-/* The same batch for callers that cannot allocate (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc); it has no
- * counterpart in the reference.  Inputs and the output are device memory on
+/* The same batch for callers that cannot allocate (tight serving loops,
+ * harnesses that forbid hipMalloc); it has no counterpart in the reference.
+ * (Code under HIP graph capture is the other caller of that kind, but a
+ * captured call did not replay correctly when tried, so capture is NOT
+ * supported: call it on a stream, outside capture.)  Inputs and the output are device memory on
  * the context's device (n origins and directions as xyz triples, n any-hit
  * bytes or NULL, n hit records out); everything else the traversal needs lives
  * in a work array that is part of the library's code object, so the call makes
