@@ -166,6 +166,8 @@ def test_cli_multi_gpu_path_with_a_communicator_of_one(tmp_path):
     assert r2.returncode == 0, r2.stderr
     rays = [ln.split()[1] for ln in (r1.stdout + r2.stdout).splitlines() if ln.startswith("rays ")]
     assert len(rays) == 2 and rays[0] == rays[1]
+    # the acceleration structure is built once per load_scene however many devices render (src/renderer.cc:41-64)
+    assert "acceleration structure builds 1 devices 1" in r2.stdout
     x, y = image_io.load_hdr(str(a))[..., :3], image_io.load_hdr(str(b))[..., :3]
     scale = np.maximum(x.max(axis=-1, keepdims=True), 1e-6)
     assert (np.abs(x - y) <= scale / 100.0).all()      # RGBE keeps 8 bits of the largest channel
@@ -177,6 +179,7 @@ def test_cli_multi_gpu_path_with_a_communicator_of_one(tmp_path):
         assert r4.returncode == 0, r4.stderr
         y = image_io.load_hdr(str(b))[..., :3]
         assert (np.abs(x - y) <= scale / 100.0).all()
+        assert "acceleration structure builds 1 devices 2" in r4.stdout   # the second device copied the first one's scene
 
 
 @needs_cli

@@ -1,5 +1,7 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/sort_experiment.sh [launch]   -> traversal kernel time per ordering, from rocprofv3
+# Needs a developer build of the library that can write one launch's rays to a file (here, before the GPU call):
+#   tools/build_variant.sh dump -DPT_DEV_DUMP_RAYS      and run with PTGPU_LIB=$PWD/pathtracer_amd/lib/variants/libptgpu_dump.so
 set -e
 root=$GRAFT_REPO_ROOT
 out=$root/gpurun_out/sortexp
