@@ -167,7 +167,7 @@ typedef struct ptgpu_settings {
  * every measurement in this repository was taken with unless it says otherwise.  A new context starts from the
  * PTGPU_* environment variables of the same names (PTGPU_CHUNK, PTGPU_POOL_GIB, PTGPU_TRAVERSE_WAVES, PTGPU_LEAF_VOTE,
  * PTGPU_BUILD_THREADS, PTGPU_INTERSECT_CHUNK, PTGPU_PERSIST_BLOCKS, PTGPU_EXTEND=simple, PTGPU_WIDE_SPLITS=reference,
- * PTGPU_WIDE_COLLAPSE=greedy, PTGPU_TLAS=linear, PTGPU_LEAF_RECORDS=0|1, PTGPU_VERBOSE=1|2), read once in ptgpu_create so that measurement
+ * PTGPU_WIDE_COLLAPSE=greedy, PTGPU_TLAS=linear, PTGPU_LEAF_RECORDS=0|1, PTGPU_RESERVE=one-counter, PTGPU_VERBOSE=1|2), read once in ptgpu_create so that measurement
  * scripts can alternate settings around an unchanged caller; ptgpu_set_options replaces them. */
 typedef struct ptgpu_options {
     uint32_t chunk_rays;      /* camera samples per batch, 1024 .. 2^28 (default 2^26): sizes the ray pools and the launches */
@@ -190,6 +190,10 @@ typedef struct ptgpu_options {
  * The same hits to the bit either way. */
 #define PTGPU_OPT_LEAF_RECORDS 64u
 #define PTGPU_OPT_NO_LEAF_RECORDS 128u
+/* The PBR shading kernel reserves its output slots with one atomic per workgroup on ONE shared counter
+ * (PTGPU_RESERVE=one-counter) instead of eight counters feeding interleaved chunks of the output: the older form, which runs
+ * at the pace of that one counter word; kept as cross-check.  Same rays either way. */
+#define PTGPU_OPT_ONE_COUNTER 256u
 
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */

@@ -121,7 +121,7 @@ class Options(C.Structure):
 
 
 OPT_EXTEND_SIMPLE, OPT_REFERENCE_SPLITS, OPT_GREEDY_COLLAPSE, OPT_LINEAR_TLAS, OPT_VERBOSE, OPT_VERBOSE_LAUNCHES = 1, 2, 4, 8, 16, 32
-OPT_LEAF_RECORDS, OPT_NO_LEAF_RECORDS = 64, 128
+OPT_LEAF_RECORDS, OPT_NO_LEAF_RECORDS, OPT_ONE_COUNTER = 64, 128, 256
 
 
 class BvhInfo(C.Structure):

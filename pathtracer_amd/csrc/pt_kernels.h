@@ -116,8 +116,21 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
                               TraceCounters* counters, hipEvent_t between = nullptr);
 // program: 0 raycaster, 1 ambient occlusion, 2 PBR.  Appends spawned rays to `out` at *out_count.
 // single_path (PBR): at most one spawned ray per hit, chosen in proportion to its payload and reweighted.
+// What the PBR kernel needs to reserve its output slots through several counters instead of one (see pt_kernels.hip):
+// `cursors` = kShadeStreamWords words of device memory (the counters, the staged count, a failure flag; zeroed by the launcher),
+// `staging` = a ray queue of `staging_capacity` records for the fix-up of the ragged end.  The output region must have
+// room for the launch's rays + shade_stream_slack() slots.  After the launch *out_count holds the number of rays and the
+// word at cursors[kShadeStreamWords - 1] is non-zero if the staging queue was too small (the output is then incomplete).
+struct ShadeStreams {
+    uint32_t* cursors = nullptr;
+    RayQueue staging{};
+    uint32_t staging_capacity = 0;
+};
+constexpr uint32_t kShadeStreamWords = 32 * 32 + 2;  // (room for up to 32 counters, 128 bytes apart, + staged count + failure flag)
+uint32_t shade_stream_slack();
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
-                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path = false);
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path = false,
+                  const ShadeStreams* streams = nullptr);
 void launch_clear(hipStream_t st, float* p, uint64_t n);
 // planar tiled sums -> row-major RGBA: rgb = sum / divisor (samples for the mean, 1 for raw sums), a = alpha
 void launch_resolve(hipStream_t st, FrameDev fb, const CameraDev& cam, float* out_rgba, float divisor, float alpha);

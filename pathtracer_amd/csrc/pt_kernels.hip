@@ -1264,6 +1264,107 @@ __device__ __forceinline__ uint32_t block_reserve(uint32_t wave_total, uint32_t*
     return base;
 }
 
+// Reservation through several counters.  One counter word takes ~85 M atomics/s on this part (they are executed one after
+// another where the word lives), and a PBR shading launch asks once per 256 rays: 290 K times per 73.6 M-ray launch — which
+// is 3.4 ms, the duration of the kernel: whatever else it did, the PBR kernel ran at the pace of its counter (a second atomic
+// per workgroup on the same word made it five times slower).  So the workgroups of a launch reserve from kStreams counters
+// instead, workgroup b from counter b % kStreams, each counter numbering the rays of its own STREAM 0, 1, 2, ...; the
+// streams share the output region chunk-wise — stream k owns the chunks k, k + kStreams, k + 2 kStreams, ... of
+// kStreamChunk rays — so a ray's slot follows from its number in its stream by arithmetic alone (stream_slot), with no table
+// and no waiting.  What this leaves is a ragged end: the streams do not end in the same chunk and their last chunks are
+// not full.  Two small kernels close it after the launch (stream_gather_kernel, stream_scatter_kernel): the valid rays
+// beyond the last chunk row that every stream filled are gathered and written back contiguously, and the launch's total
+// goes to *out_count.  Everything downstream sees the dense queue it always saw.
+#ifndef PT_STREAMS_LOG2
+#define PT_STREAMS_LOG2 3
+#endif
+#ifndef PT_STREAM_CHUNK_LOG2
+#define PT_STREAM_CHUNK_LOG2 14
+#endif
+constexpr uint32_t kStreamsLog2 = PT_STREAMS_LOG2, kStreams = 1u << kStreamsLog2;
+constexpr uint32_t kStreamChunkLog2 = PT_STREAM_CHUNK_LOG2, kStreamChunk = 1u << kStreamChunkLog2;
+constexpr uint32_t kStreamCursorStride = 32;  // cursors sit 128 bytes apart
+__host__ __device__ __forceinline__ uint32_t stream_slot(uint32_t stream, uint32_t number) {
+    return ((((number >> kStreamChunkLog2) << kStreamsLog2) | stream) << kStreamChunkLog2) | (number & (kStreamChunk - 1u));
+}
+struct Reservation {
+    uint32_t* out_count;  // the shared counter (streams == nullptr), else written by the fix-up
+    uint32_t* streams;    // kStreams cursors, kStreamCursorStride words apart, zeroed before the launch; or null
+};
+// Reserves `wave_total` consecutive numbers for the calling wavefront; returns the first.  With streams they are numbers in
+// the workgroup's stream (turn each into a slot with queue_slot), else slots.  Every thread of the workgroup must call it.
+template <int BLOCK = kBlock>
+__device__ __forceinline__ uint32_t reserve_slots(uint32_t wave_total, const Reservation& r) {
+    return block_reserve<BLOCK>(wave_total, r.streams ? r.streams + (blockIdx.x & (kStreams - 1u)) * kStreamCursorStride : r.out_count);
+}
+__device__ __forceinline__ uint32_t queue_slot(const Reservation& r, uint32_t number) {
+    return r.streams ? stream_slot(blockIdx.x & (kStreams - 1u), number) : number;
+}
+
+// The ragged end of a launch reserved through streams.  `row0` = the number of chunk rows that every stream filled
+// completely: all slots below row0 * kStreams * kStreamChunk hold rays.  Beyond, a slot holds a ray iff its number in its
+// stream is below that stream's cursor.
+struct StreamEnd {
+    uint32_t first;  // first slot of the ragged zone
+    uint32_t end;    // one past its last slot
+    uint32_t pos[kStreams];
+};
+__device__ __forceinline__ StreamEnd stream_end(const uint32_t* __restrict__ streams) {
+    StreamEnd e;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kStreams; ++k) {
+        e.pos[k] = streams[k * kStreamCursorStride];
+        const uint32_t full = e.pos[k] >> kStreamChunkLog2, used = (e.pos[k] + kStreamChunk - 1u) >> kStreamChunkLog2;
+        lo = full < lo ? full : lo;
+        hi = used > hi ? used : hi;
+    }
+    e.first = lo << (kStreamsLog2 + kStreamChunkLog2);
+    e.end = hi << (kStreamsLog2 + kStreamChunkLog2);
+    return e;
+}
+// Pass 1: the zone's rays, in any order, to a staging queue (one atomic per workgroup on *staged).
+__global__ __launch_bounds__(kBlock) void stream_gather_kernel(RayQueue q, const uint32_t* __restrict__ streams, RayQueue staging,
+                                                               uint32_t staging_capacity, uint32_t* __restrict__ staged,
+                                                               uint32_t* __restrict__ failed) {
+    const StreamEnd e = stream_end(streams);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t s0 = e.first + blockIdx.x * kBlock; s0 < e.end; s0 += gridDim.x * kBlock) {  // (uniform per workgroup: every thread reaches the barriers)
+        const uint32_t s = s0 + threadIdx.x;
+        const uint32_t k = (s >> kStreamChunkLog2) & (kStreams - 1u);
+        const uint32_t number = ((s >> (kStreamsLog2 + kStreamChunkLog2)) << kStreamChunkLog2) | (s & (kStreamChunk - 1u));
+        uint32_t pos = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kStreams; ++j) pos = (j == k) ? e.pos[j] : pos;
+        const bool valid = s < e.end && number < pos;
+        const unsigned long long m = __ballot(valid);
+        const uint32_t base = block_reserve(static_cast<uint32_t>(__popcll(m)), staged);
+        if (valid) {
+            const uint32_t dst = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (dst < staging_capacity) {
+                staging.o[dst] = q.o[s];
+                staging.d[dst] = q.d[s];
+                staging.p[dst] = q.p[s];
+            } else {
+                atomicOr(failed, 1u);
+            }
+        }
+    }
+}
+// Pass 2: back, contiguously, from the zone's first slot on; the launch's total to *out_count.
+__global__ __launch_bounds__(kBlock) void stream_scatter_kernel(RayQueue q, const uint32_t* __restrict__ streams, RayQueue staging,
+                                                                uint32_t staging_capacity, const uint32_t* __restrict__ staged,
+                                                                uint32_t* __restrict__ out_count) {
+    const StreamEnd e = stream_end(streams);
+    const uint32_t n = *staged < staging_capacity ? *staged : staging_capacity;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        q.o[e.first + i] = staging.o[i];
+        q.d[e.first + i] = staging.d[i];
+        q.p[e.first + i] = staging.p[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = e.first + n;
+}
+
 // DENSE: the frame is a whole number of tiles, so every lane has a pixel and ray i goes to slot i — no compaction, no
 // queue atomic (one per workgroup is ~100 M/s at this kernel's rate, more than one counter word sustains).
 template <bool DENSE>
@@ -1698,7 +1799,7 @@ __device__ __forceinline__ float lobe_weight(f3 p) {
 
 template <bool SINGLE, bool ALL_LDS>
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
-                                                           RayQueue out, uint32_t* __restrict__ out_count, FrameDev fb) {
+                                                           RayQueue out, Reservation res, FrameDev fb) {
     // Three stages, so that no spawned ray has to wait in registers for the others:
     //   A  everything up to the point where it is known WHICH of the four lobes spawn a ray (that needs the tangent
     //      frame, the micro-normal and the refracted direction);
@@ -1803,7 +1904,8 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
 
     const uint32_t lane_id = threadIdx.x & 63u;
     const unsigned long long lt = (1ull << lane_id) - 1ull;
-    auto store = [&](uint32_t dst, f3 org, float4 d4, f3 pl, uint32_t lobe) {
+    auto store = [&](uint32_t number, f3 org, float4 d4, f3 pl, uint32_t lobe) {
+        const uint32_t dst = queue_slot(res, number);
         out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of()));
         out.d[dst] = d4;
         out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
@@ -1873,7 +1975,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             offs[s] = total + __popcll(mask & lt);
             total += __popcll(mask);
         }
-        const uint32_t base = block_reserve<kShadeBlock>(total, out_count);
+        const uint32_t base = reserve_slots<kShadeBlock>(total, res);
         lobes([&](auto s, f3 org, float4 d4, f3 pl, uint32_t lobe) { store(base + offs[decltype(s)::value], org, d4, pl, lobe); });
     } else {
         f3 org0 = mk3(0.0f), org1 = org0, org2 = org0, org3 = org0, pl0 = org0, pl1 = org0, pl2 = org0, pl3 = org0;
@@ -1904,7 +2006,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const float4 d4 = (pick == 0) ? d0 : (pick == 1) ? d1 : (pick == 2) ? d2 : d3;
         const f3 pl = (pick == 0) ? pl0 : (pick == 1) ? pl1 : (pick == 2) ? pl2 : pl3;
         const unsigned long long mask = __ballot(any);
-        const uint32_t base = block_reserve<kShadeBlock>(__popcll(mask), out_count);
+        const uint32_t base = reserve_slots<kShadeBlock>(__popcll(mask), res);
         if (any) store(base + __popcll(mask & lt), org, d4, pl * (total_w / wp), static_cast<uint32_t>(pick));
     }
 }
@@ -2092,8 +2194,9 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
                            spill_depth, stride, counters);
     }
 }
+uint32_t shade_stream_slack() { return kStreams * (kStreamChunk + 8u * kShadeBlock); }
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
-                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path) {
+                  uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path, const ShadeStreams* streams) {
     if (!n) return;
     const dim3 grid(blocks_for(n)), block(kBlock);
     const bool all_lds = sc.n_instances <= kObjLds;  // every object record is in the kernel's LDS copy
@@ -2102,10 +2205,26 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
         else PT_LAUNCH(shade_ao_kernel<false>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
     } else if (program == 2) {
         const dim3 g((n + kShadeBlock - 1) / kShadeBlock), b(kShadeBlock);
-        if (single_path && all_lds) PT_LAUNCH((shade_pbr_kernel<true, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
-        else if (single_path) PT_LAUNCH((shade_pbr_kernel<true, false>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
-        else if (all_lds) PT_LAUNCH((shade_pbr_kernel<false, true>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
-        else PT_LAUNCH((shade_pbr_kernel<false, false>), g, b, 0, st, sc, rays, n, hits, out, out_count, fb);
+        // launches of few workgroups are far from the counter's rate: they keep the single counter and need no fix-up
+        const bool use_streams = streams && streams->cursors && g.x >= 4096u;
+        const Reservation res{out_count, use_streams ? streams->cursors : nullptr};
+        if (use_streams) {
+            const hipError_t e = hipMemsetAsync(streams->cursors, 0, kShadeStreamWords * sizeof(uint32_t), st);
+            if (e != hipSuccess && g_launch_error == hipSuccess) {
+                g_launch_error = e;
+                g_launch_kernel = "hipMemsetAsync of the reservation cursors";
+            }
+        }
+        if (single_path && all_lds) PT_LAUNCH((shade_pbr_kernel<true, true>), g, b, 0, st, sc, rays, n, hits, out, res, fb);
+        else if (single_path) PT_LAUNCH((shade_pbr_kernel<true, false>), g, b, 0, st, sc, rays, n, hits, out, res, fb);
+        else if (all_lds) PT_LAUNCH((shade_pbr_kernel<false, true>), g, b, 0, st, sc, rays, n, hits, out, res, fb);
+        else PT_LAUNCH((shade_pbr_kernel<false, false>), g, b, 0, st, sc, rays, n, hits, out, res, fb);
+        if (use_streams) {  // close the ragged end: the last two of the cursor words are the staged count and the failure flag
+            uint32_t* staged = streams->cursors + kShadeStreamWords - 2u;
+            const dim3 gf(1024);
+            PT_LAUNCH(stream_gather_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, streams->staging_capacity, staged, staged + 1);
+            PT_LAUNCH(stream_scatter_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, streams->staging_capacity, staged, out_count);
+        }
     } else
         PT_LAUNCH(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
 }

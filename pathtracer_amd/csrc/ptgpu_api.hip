@@ -197,6 +197,8 @@ struct ptgpu_ctx {
     uint32_t launch_cap = 0;       // rays per launch the work buffers are sized for (also the candidate list stride)
     Pool pools[2];
     DevBuf hit0, hit1, spill, fb, subs, counter, trace_counters, out_rgba, ray_cursor, cand, overflow;
+    DevBuf stream_cursors, staging_o, staging_d, staging_p;  // the PBR kernel's multi-counter reservation (launch_shade)
+    static constexpr uint32_t kStagingRays = 1u << 22;       // rays the fix-up of a launch's ragged end can hold
     bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
     uint32_t persist_blocks = 0;   // resident workgroups of the persistent extend kernel
     uint32_t* host_counter = nullptr;  // pinned
@@ -265,6 +267,7 @@ ptgpu_options options_from_environment() {
     if (is("PTGPU_WIDE_SPLITS", "reference")) o.flags |= PTGPU_OPT_REFERENCE_SPLITS;
     if (is("PTGPU_WIDE_COLLAPSE", "greedy")) o.flags |= PTGPU_OPT_GREEDY_COLLAPSE;
     if (is("PTGPU_TLAS", "linear")) o.flags |= PTGPU_OPT_LINEAR_TLAS;
+    if (is("PTGPU_RESERVE", "one-counter")) o.flags |= PTGPU_OPT_ONE_COUNTER;
     if (is("PTGPU_LEAF_RECORDS", "1")) o.flags |= PTGPU_OPT_LEAF_RECORDS;
     if (is("PTGPU_LEAF_RECORDS", "0")) o.flags |= PTGPU_OPT_NO_LEAF_RECORDS;
     const uint32_t verbose = number("PTGPU_VERBOSE", 1, 9);
@@ -339,11 +342,12 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     L = std::max<uint64_t>(std::max<uint64_t>(L, K), c->launch_cap);
     // live rays per generation are bounded by fanout * chunk; generations alternate between the pools
     uint64_t gens = std::min<uint64_t>(bounces, 254) / 2 + 2;
-    uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens;
+    // (+ the slots a launch of the PBR kernel may leave unused at the end of its output before its ragged end is closed)
+    uint64_t cap = K + static_cast<uint64_t>(fanout) * K * gens + (fanout ? ptd::shade_stream_slack() : 0u);
     // at most 32 GiB per pool (ptgpu_options.pool_gib overrides); the scheduler splits segments beyond that
     const uint64_t pool_gib = c->options.pool_gib ? c->options.pool_gib : 32;
     const uint64_t cap_limit = (pool_gib << 30) / 48;
-    cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64));
+    cap = std::min(cap, std::max<uint64_t>(cap_limit, K + static_cast<uint64_t>(fanout) * 64 + (fanout ? ptd::shade_stream_slack() : 0u)));
     // A failed allocation leaves its buffer empty (ensure frees first).  The sizes recorded in the context must never
     // claim more than the buffers hold, so they are cleared before anything is touched and set again once all of it is there.
     c->batch_cap = 0;
@@ -371,6 +375,12 @@ int ensure_work_memory(ptgpu_ctx* c, uint32_t fanout, uint32_t bounces, uint64_t
     if (c->persistent) PT_HIP(c, c->cand.ensure(static_cast<size_t>(ptd::kCandMax) * L * sizeof(uint2)));
     if (c->persistent) PT_HIP(c, c->overflow.ensure((L + 1) * sizeof(uint32_t)));
     PT_HIP(c, c->counter.ensure(16));
+    if (fanout && !(c->options.flags & PTGPU_OPT_ONE_COUNTER)) {
+        PT_HIP(c, c->stream_cursors.ensure(ptd::kShadeStreamWords * sizeof(uint32_t)));
+        PT_HIP(c, c->staging_o.ensure(static_cast<size_t>(ptgpu_ctx::kStagingRays) * 16));
+        PT_HIP(c, c->staging_d.ensure(static_cast<size_t>(ptgpu_ctx::kStagingRays) * 16));
+        PT_HIP(c, c->staging_p.ensure(static_cast<size_t>(ptgpu_ctx::kStagingRays) * 16));
+    }
     PT_HIP(c, c->trace_counters.ensure(sizeof(ptd::TraceCounters)));
     c->batch_cap = static_cast<uint32_t>(K);
     c->launch_cap = static_cast<uint32_t>(L);
@@ -453,6 +463,14 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     ptd::SceneDev sc = c->scene;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     uint32_t* d_count = c->counter.as<uint32_t>();
+    ptd::ShadeStreams streams;
+    const bool use_streams = fanout && program == PTGPU_PROGRAM_PBR && !(c->options.flags & PTGPU_OPT_ONE_COUNTER);
+    if (use_streams) {
+        streams.cursors = c->stream_cursors.as<uint32_t>();
+        streams.staging = ptd::RayQueue{c->staging_o.as<float4>(), c->staging_d.as<float4>(), c->staging_p.as<float4>()};
+        streams.staging_capacity = ptgpu_ctx::kStagingRays;
+    }
+    const uint64_t stream_slack = use_streams ? ptd::shade_stream_slack() : 0u;
 
     ptgpu_stats out{};
     PT_HIP(c, hipEventRecord(c->ev[4], st));
@@ -523,7 +541,9 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             }
             uint64_t n64 = std::min<uint64_t>(L, in.top - f.floor_in);
             if (fanout) {
-                const uint64_t room = (op.cap - op.top) / fanout;
+                // (the PBR kernel's output may end up to stream_slack slots past its rays before the ragged end is closed)
+                const uint64_t free_slots = op.cap - op.top;
+                const uint64_t room = (free_slots > stream_slack ? free_slots - stream_slack : 0) / fanout;
                 if (room < std::min<uint64_t>(n64, kMinLaunch)) {
                     if (op.top > f.floor_out) {
                         frames.push_back({f.pool ^ 1, f.floor_out, in.top});  // depth first: drain the spawned rays, then resume
@@ -559,10 +579,15 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             if (fanout) PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
             PT_HIP(c, hipEventRecord(c->ev[2], st));
             ptd::launch_shade(st, program, sc, rq, n, hits, op.at(op.top), d_count, fb, ao_samples,
-                              (s.flags & PTGPU_FLAG_SINGLE_PATH) != 0);
+                              (s.flags & PTGPU_FLAG_SINGLE_PATH) != 0, use_streams ? &streams : nullptr);
             PT_HIP(c, hipEventRecord(c->ev[3], st));
             if (fanout) PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
+            if (use_streams)  // (zeroed by the launcher only when the launch went through the streams: cleared here otherwise)
+                PT_HIP(c, hipMemcpyAsync(c->host_counter + 1, streams.cursors + ptd::kShadeStreamWords - 1, 4, hipMemcpyDeviceToHost, st));
             PT_SYNC(c, st);
+            if (use_streams && n >= 4096u * 256u && c->host_counter[1] != 0)
+                return c->fail(PTGPU_E_NOMEM, "shade launch %llu: the ragged end of its output did not fit the staging queue (%u rays)",
+                               static_cast<unsigned long long>(out.shade_launches), ptgpu_ctx::kStagingRays);
             PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
             out.extend_ms += ms;
             if (c->persistent) {
@@ -723,7 +748,7 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
 int ptgpu_set_options(ptgpu_ctx* c, const ptgpu_options* o) {
     if (!c || !o) return PTGPU_E_INVALID;
     if (o->flags & ~(PTGPU_OPT_EXTEND_SIMPLE | PTGPU_OPT_REFERENCE_SPLITS | PTGPU_OPT_GREEDY_COLLAPSE | PTGPU_OPT_LINEAR_TLAS |
-                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES | PTGPU_OPT_LEAF_RECORDS | PTGPU_OPT_NO_LEAF_RECORDS))
+                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES | PTGPU_OPT_LEAF_RECORDS | PTGPU_OPT_NO_LEAF_RECORDS | PTGPU_OPT_ONE_COUNTER))
         return c->fail(PTGPU_E_INVALID, "set_options: unknown flag bits 0x%x", o->flags);
     if ((o->chunk_rays && (o->chunk_rays < 1024 || o->chunk_rays > (1u << 28))) || o->pool_gib > 256 ||
         (o->traverse_waves && o->traverse_waves != 6 && o->traverse_waves != 7) || o->leaf_vote > 16 || o->build_threads > 64)

@@ -481,6 +481,32 @@ def test_leaf_records_change_no_result(materials, scene):
     assert exact.mean() >= 0.9999
 
 
+@pytest.mark.parametrize("single", [False, True])
+def test_output_slots_through_several_counters(materials, single):
+    """The PBR kernel reserves its output slots from eight counters that feed interleaved chunks of the output region, and two
+    small kernels close the ragged end afterwards (one counter word takes ~85 M atomics/s, which was the kernel's pace).
+    Launches of a million rays and more take that path: the frame has the oracle's ray count and pixels, and equals the frame
+    rendered through the single counter (PTGPU_OPT_ONE_COUNTER) — also when the pools are so small that launches are cut and
+    spawned rays are drained depth first."""
+    model, env = materials
+    w, h, spp = 512, 288, 10        # 1.47 M camera rays: every generation down to ~1 M rays goes through the streams
+    st = H.settings(program=2, spp=spp, bounces=4, single=single)
+    streams = H.make_gpu(model, env, st, w, h)
+    img_s, s_s = H.gpu_render(streams, w, h)
+    one = H.make_gpu(model, env, st, w, h, flags=abi.OPT_ONE_COUNTER)
+    img_1, s_1 = H.gpu_render(one, w, h)
+    assert s_s.rays == s_1.rays and s_s.camera_samples == w * h * spp
+    assert np.allclose(img_s, img_1, rtol=2e-5, atol=2e-6)
+    tight = H.make_gpu(model, env, st, w, h, chunk_rays=1 << 20, pool_gib=1)
+    img_t, s_t = H.gpu_render(tight, w, h)
+    assert s_t.rays == s_s.rays and np.allclose(img_t, img_s, rtol=2e-5, atol=2e-6)
+    o = H.make_oracle(model, env, st, w, h)
+    rows = (140, 148)
+    band, so = o.render_frame(w, h, rows=rows)
+    d = np.abs(img_s[rows[0]:rows[1], :, :3] - band[rows[0]:rows[1], :, :3])
+    assert (d <= 2e-5 * np.maximum(1.0, band[rows[0]:rows[1], :, :3])).all(), d.max()
+
+
 @pytest.mark.parametrize("seed,offset,flat", [(1, 0.0, False), (2, 0.0, True), (3, 300.0, False), (4, 5000.0, True)])
 def test_random_soups_both_node_layouts(seed, offset, flat):
     """Unstructured triangle soups under random affine transforms, also far from the object-space origin (box planes and
