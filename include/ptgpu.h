@@ -194,6 +194,10 @@ typedef struct ptgpu_options {
  * (PTGPU_RESERVE=one-counter) instead of eight counters feeding interleaved chunks of the output: the older form, which runs
  * at the pace of that one counter word; kept as cross-check.  Same rays either way. */
 #define PTGPU_OPT_ONE_COUNTER 256u
+/* The staging queue that closes the ragged end of a launch reserved through the eight counters holds 32 Ki rays instead of
+ * 4 Mi, so that every such launch takes the piecewise path a real frame needs only when its streams end megarays apart: for
+ * tests of that path. */
+#define PTGPU_OPT_SMALL_STAGING 512u
 
 /* Per-pixel primary-ray hit record, the `ray_triangle_hit_info` of
  * src/ray_program.h:29-56 (raycast parity dump). */
@@ -228,7 +232,8 @@ typedef struct ptgpu_stats {
     uint64_t nodes_from_lds; /* ptgpu_render_counted: node visits served by the traversal kernel's LDS copy of the top nodes */
     uint32_t traverse_workgroups_per_cu; /* form of the traversal kernel the loaded scene runs with: 6, or 7 (four-wide nodes
                                             over a scene the caches hold); 0 with PTGPU_EXTEND=simple */
-    uint32_t reserved0;
+    uint32_t ragged_end_in_pieces; /* PBR launches whose output streams ended too far apart for the one-piece fix-up (see
+                                      PTGPU_OPT_SMALL_STAGING): closed piece by piece, slower, same rays */
     uint64_t leaf_records_read; /* ptgpu_render_counted, scenes whose four-wide leaves are 64-byte records: records fetched (0 otherwise) */
 } ptgpu_stats;
 

@@ -109,7 +109,7 @@ class Stats(C.Structure):
         ("generate_ms", C.c_double), ("total_ms", C.c_double), ("nodes_visited", C.c_uint64),
         ("triangles_tested", C.c_uint64), ("instances_tested", C.c_uint64), ("instances_entered", C.c_uint64),
         ("wave_inner_iterations", C.c_uint64), ("wave_triangle_iterations", C.c_uint64),
-        ("traverse_ms", C.c_double), ("nodes_from_lds", C.c_uint64), ("traverse_workgroups_per_cu", C.c_uint32), ("reserved0", C.c_uint32),
+        ("traverse_ms", C.c_double), ("nodes_from_lds", C.c_uint64), ("traverse_workgroups_per_cu", C.c_uint32), ("ragged_end_in_pieces", C.c_uint32),
         ("leaf_records_read", C.c_uint64),
     ]
 
@@ -121,7 +121,7 @@ class Options(C.Structure):
 
 
 OPT_EXTEND_SIMPLE, OPT_REFERENCE_SPLITS, OPT_GREEDY_COLLAPSE, OPT_LINEAR_TLAS, OPT_VERBOSE, OPT_VERBOSE_LAUNCHES = 1, 2, 4, 8, 16, 32
-OPT_LEAF_RECORDS, OPT_NO_LEAF_RECORDS, OPT_ONE_COUNTER = 64, 128, 256
+OPT_LEAF_RECORDS, OPT_NO_LEAF_RECORDS, OPT_ONE_COUNTER, OPT_SMALL_STAGING = 64, 128, 256, 512
 
 
 class BvhInfo(C.Structure):

@@ -120,7 +120,8 @@ void launch_extend_persistent(hipStream_t st, const SceneDev& sc, RayQueue rays,
 // `cursors` = kShadeStreamWords words of device memory (the counters, the staged count, a failure flag; zeroed by the launcher),
 // `staging` = a ray queue of `staging_capacity` records for the fix-up of the ragged end.  The output region must have
 // room for the launch's rays + shade_stream_slack() slots.  After the launch *out_count holds the number of rays and the
-// word at cursors[kShadeStreamWords - 1] is non-zero if the staging queue was too small (the output is then incomplete).
+// word at cursors[kShadeStreamWords - 1] is non-zero if the staging queue was too small: the rays are all there, *out_count
+// is not, and close_ragged_end_piecewise finishes the job.
 struct ShadeStreams {
     uint32_t* cursors = nullptr;
     RayQueue staging{};
@@ -128,6 +129,11 @@ struct ShadeStreams {
 };
 constexpr uint32_t kShadeStreamWords = 32 * 32 + 2;  // (room for up to 32 counters, 128 bytes apart, + staged count + failure flag)
 uint32_t shade_stream_slack();
+// Whether launch_shade reserves this launch's output through the streams (only then are the cursor words rewritten).
+bool shade_reserves_through_streams(int program, uint32_t n, const ShadeStreams* streams);
+// For a launch whose failure word came back set: closes the ragged end in pieces the staging queue can hold (synchronises
+// the stream once per piece).  *total and *out_count = the launch's rays.
+hipError_t close_ragged_end_piecewise(hipStream_t st, RayQueue out, uint32_t* out_count, const ShadeStreams& streams, uint32_t* total);
 void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays, uint32_t n, HitQueue hits, RayQueue out,
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path = false,
                   const ShadeStreams* streams = nullptr);

@@ -1325,20 +1325,23 @@ __device__ __forceinline__ StreamEnd stream_end(const uint32_t* __restrict__ str
     e.end = hi << (kStreamsLog2 + kStreamChunkLog2);
     return e;
 }
-// Pass 1: the zone's rays, in any order, to a staging queue (one atomic per workgroup on *staged).
+// Pass 1: the rays of the zone's slots [first + from, first + from + slots), in any order, to a staging queue (one atomic
+// per workgroup on *staged).  If they do not fit, *failed is set and pass 2 leaves the queue as it is.
 __global__ __launch_bounds__(kBlock) void stream_gather_kernel(RayQueue q, const uint32_t* __restrict__ streams, RayQueue staging,
                                                                uint32_t staging_capacity, uint32_t* __restrict__ staged,
-                                                               uint32_t* __restrict__ failed) {
+                                                               uint32_t* __restrict__ failed, uint32_t from, uint32_t slots) {
     const StreamEnd e = stream_end(streams);
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t s0 = e.first + blockIdx.x * kBlock; s0 < e.end; s0 += gridDim.x * kBlock) {  // (uniform per workgroup: every thread reaches the barriers)
+    const uint32_t begin = e.first + from;  // (from <= end - first: the launcher's pieces stay inside the zone)
+    const uint32_t end = slots < e.end - begin ? begin + slots : e.end;
+    for (uint32_t s0 = begin + blockIdx.x * kBlock; s0 < end; s0 += gridDim.x * kBlock) {  // (uniform per workgroup: every thread reaches the barriers)
         const uint32_t s = s0 + threadIdx.x;
         const uint32_t k = (s >> kStreamChunkLog2) & (kStreams - 1u);
         const uint32_t number = ((s >> (kStreamsLog2 + kStreamChunkLog2)) << kStreamChunkLog2) | (s & (kStreamChunk - 1u));
         uint32_t pos = 0;
 #pragma unroll
         for (uint32_t j = 0; j < kStreams; ++j) pos = (j == k) ? e.pos[j] : pos;
-        const bool valid = s < e.end && number < pos;
+        const bool valid = s < end && number < pos;
         const unsigned long long m = __ballot(valid);
         const uint32_t base = block_reserve(static_cast<uint32_t>(__popcll(m)), staged);
         if (valid) {
@@ -1353,18 +1356,19 @@ __global__ __launch_bounds__(kBlock) void stream_gather_kernel(RayQueue q, const
         }
     }
 }
-// Pass 2: back, contiguously, from the zone's first slot on; the launch's total to *out_count.
+// Pass 2: back, contiguously, from slot first + to on; the total so far to *out_count.
 __global__ __launch_bounds__(kBlock) void stream_scatter_kernel(RayQueue q, const uint32_t* __restrict__ streams, RayQueue staging,
-                                                                uint32_t staging_capacity, const uint32_t* __restrict__ staged,
-                                                                uint32_t* __restrict__ out_count) {
+                                                                const uint32_t* __restrict__ staged, const uint32_t* __restrict__ failed,
+                                                                uint32_t to, uint32_t* __restrict__ out_count) {
+    if (*failed) return;  // (uniform) the staged rays are not all of the piece: the launcher goes piece by piece instead
     const StreamEnd e = stream_end(streams);
-    const uint32_t n = *staged < staging_capacity ? *staged : staging_capacity;
+    const uint32_t n = *staged, first = e.first + to;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        q.o[e.first + i] = staging.o[i];
-        q.d[e.first + i] = staging.d[i];
-        q.p[e.first + i] = staging.p[i];
+        q.o[first + i] = staging.o[i];
+        q.d[first + i] = staging.d[i];
+        q.p[first + i] = staging.p[i];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = e.first + n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *out_count = first + n;
 }
 
 // DENSE: the frame is a whole number of tiles, so every lane has a pixel and ray i goes to slot i — no compaction, no
@@ -2224,11 +2228,48 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
         if (use_streams) {  // close the ragged end: the last two of the cursor words are the staged count and the failure flag
             uint32_t* staged = streams->cursors + kShadeStreamWords - 2u;
             const dim3 gf(1024);
-            PT_LAUNCH(stream_gather_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, streams->staging_capacity, staged, staged + 1);
-            PT_LAUNCH(stream_scatter_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, streams->staging_capacity, staged, out_count);
+            PT_LAUNCH(stream_gather_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, streams->staging_capacity, staged, staged + 1,
+                      0u, 0xffffffffu);
+            PT_LAUNCH(stream_scatter_kernel, gf, block, 0, st, out, streams->cursors, streams->staging, staged, staged + 1, 0u, out_count);
         }
     } else
         PT_LAUNCH(shade_raycast_kernel, grid, block, 0, st, sc, rays, n, hits, fb);
+}
+bool shade_reserves_through_streams(int program, uint32_t n, const ShadeStreams* streams) {
+    return program == 2 && streams && streams->cursors && (n + kShadeBlock - 1) / kShadeBlock >= 4096u;
+}
+hipError_t close_ragged_end_piecewise(hipStream_t st, RayQueue out, uint32_t* out_count, const ShadeStreams& streams, uint32_t* total) {
+    // The streams ended so far apart that the ragged zone's rays did not fit the staging queue in one piece (pass 2 has
+    // left the queue alone).  The zone is compacted in place, in pieces of as many SLOTS as the staging queue holds rays:
+    // a piece's rays are staged, then written where the previous piece's ended — never past the piece's own first slot.
+    uint32_t pos[kStreams];
+    for (uint32_t k = 0; k < kStreams; ++k) {
+        const hipError_t e = hipMemcpyAsync(&pos[k], streams.cursors + k * kStreamCursorStride, 4, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (uint32_t k = 0; k < kStreams; ++k) {
+        lo = std::min(lo, pos[k] >> kStreamChunkLog2);
+        hi = std::max(hi, (pos[k] + kStreamChunk - 1u) >> kStreamChunkLog2);
+    }
+    const uint32_t zone = (hi - lo) << (kStreamsLog2 + kStreamChunkLog2);
+    uint32_t* staged = streams.cursors + kShadeStreamWords - 2u;
+    const dim3 gf(1024), block(kBlock);
+    uint32_t written = 0;  // rays written back so far = offset of the next piece's destination in the zone
+    for (uint32_t from = 0; from < zone; from += streams.staging_capacity) {
+        if ((e = hipMemsetAsync(staged, 0, 8, st)) != hipSuccess) return e;  // the staged count and the failure flag
+        PT_LAUNCH(stream_gather_kernel, gf, block, 0, st, out, streams.cursors, streams.staging, streams.staging_capacity, staged, staged + 1, from,
+                  streams.staging_capacity);
+        PT_LAUNCH(stream_scatter_kernel, gf, block, 0, st, out, streams.cursors, streams.staging, staged, staged + 1, written, out_count);
+        uint32_t n = 0;
+        if ((e = hipMemcpyAsync(&n, staged, 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        written += n;
+    }
+    *total = (lo << (kStreamsLog2 + kStreamChunkLog2)) + written;  // (what the last piece's pass 2 wrote to *out_count)
+    return hipSuccess;
 }
 void launch_clear(hipStream_t st, float* p, uint64_t n) {
     if (!n) return;

@@ -468,7 +468,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     if (use_streams) {
         streams.cursors = c->stream_cursors.as<uint32_t>();
         streams.staging = ptd::RayQueue{c->staging_o.as<float4>(), c->staging_d.as<float4>(), c->staging_p.as<float4>()};
-        streams.staging_capacity = ptgpu_ctx::kStagingRays;
+        streams.staging_capacity = (c->options.flags & PTGPU_OPT_SMALL_STAGING) ? (1u << 15) : ptgpu_ctx::kStagingRays;
     }
     const uint64_t stream_slack = use_streams ? ptd::shade_stream_slack() : 0u;
 
@@ -582,12 +582,16 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
                               (s.flags & PTGPU_FLAG_SINGLE_PATH) != 0, use_streams ? &streams : nullptr);
             PT_HIP(c, hipEventRecord(c->ev[3], st));
             if (fanout) PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
-            if (use_streams)  // (zeroed by the launcher only when the launch went through the streams: cleared here otherwise)
+            const bool through_streams = ptd::shade_reserves_through_streams(program, n, use_streams ? &streams : nullptr);
+            if (through_streams)
                 PT_HIP(c, hipMemcpyAsync(c->host_counter + 1, streams.cursors + ptd::kShadeStreamWords - 1, 4, hipMemcpyDeviceToHost, st));
             PT_SYNC(c, st);
-            if (use_streams && n >= 4096u * 256u && c->host_counter[1] != 0)
-                return c->fail(PTGPU_E_NOMEM, "shade launch %llu: the ragged end of its output did not fit the staging queue (%u rays)",
-                               static_cast<unsigned long long>(out.shade_launches), ptgpu_ctx::kStagingRays);
+            if (through_streams && c->host_counter[1] != 0) {
+                // the streams ended further apart than the staging queue holds (a launch whose workgroups' yields follow
+                // their position modulo the number of streams): slower, piece by piece
+                PT_HIP(c, ptd::close_ragged_end_piecewise(st, op.at(op.top), d_count, streams, c->host_counter));
+                ++out.ragged_end_in_pieces;
+            }
             PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
             out.extend_ms += ms;
             if (c->persistent) {
@@ -748,7 +752,7 @@ int ptgpu_set_render_settings(ptgpu_ctx* c, const ptgpu_settings* s) {
 int ptgpu_set_options(ptgpu_ctx* c, const ptgpu_options* o) {
     if (!c || !o) return PTGPU_E_INVALID;
     if (o->flags & ~(PTGPU_OPT_EXTEND_SIMPLE | PTGPU_OPT_REFERENCE_SPLITS | PTGPU_OPT_GREEDY_COLLAPSE | PTGPU_OPT_LINEAR_TLAS |
-                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES | PTGPU_OPT_LEAF_RECORDS | PTGPU_OPT_NO_LEAF_RECORDS | PTGPU_OPT_ONE_COUNTER))
+                     PTGPU_OPT_VERBOSE | PTGPU_OPT_VERBOSE_LAUNCHES | PTGPU_OPT_LEAF_RECORDS | PTGPU_OPT_NO_LEAF_RECORDS | PTGPU_OPT_ONE_COUNTER | PTGPU_OPT_SMALL_STAGING))
         return c->fail(PTGPU_E_INVALID, "set_options: unknown flag bits 0x%x", o->flags);
     if ((o->chunk_rays && (o->chunk_rays < 1024 || o->chunk_rays > (1u << 28))) || o->pool_gib > 256 ||
         (o->traverse_waves && o->traverse_waves != 6 && o->traverse_waves != 7) || o->leaf_vote > 16 || o->build_threads > 64)

@@ -487,7 +487,7 @@ def test_output_slots_through_several_counters(materials, single):
     small kernels close the ragged end afterwards (one counter word takes ~85 M atomics/s, which was the kernel's pace).
     Launches of a million rays and more take that path: the frame has the oracle's ray count and pixels, and equals the frame
     rendered through the single counter (PTGPU_OPT_ONE_COUNTER) — also when the pools are so small that launches are cut and
-    spawned rays are drained depth first."""
+    spawned rays are drained depth first, and when the ragged end does not fit the staging queue in one piece."""
     model, env = materials
     w, h, spp = 512, 288, 10        # 1.47 M camera rays: every generation down to ~1 M rays goes through the streams
     st = H.settings(program=2, spp=spp, bounces=4, single=single)
@@ -500,6 +500,12 @@ def test_output_slots_through_several_counters(materials, single):
     tight = H.make_gpu(model, env, st, w, h, chunk_rays=1 << 20, pool_gib=1)
     img_t, s_t = H.gpu_render(tight, w, h)
     assert s_t.rays == s_s.rays and np.allclose(img_t, img_s, rtol=2e-5, atol=2e-6)
+    assert s_s.ragged_end_in_pieces == 0 and s_1.ragged_end_in_pieces == 0
+    # a staging queue far smaller than the ragged zone: the zone is compacted in place, piece by piece
+    pieces = H.make_gpu(model, env, st, w, h, flags=abi.OPT_SMALL_STAGING)
+    img_p, s_p = H.gpu_render(pieces, w, h)
+    assert s_p.ragged_end_in_pieces > 0
+    assert s_p.rays == s_s.rays and np.allclose(img_p, img_s, rtol=2e-5, atol=2e-6)
     o = H.make_oracle(model, env, st, w, h)
     rows = (140, 148)
     band, so = o.render_frame(w, h, rows=rows)
