@@ -446,14 +446,10 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
     const float4 ro = ray_o[gid], rd = ray_d[gid];
     const bool any_hit = ((__float_as_uint(rd.w) >> 8) & 1u) != 0;
     const DopRay pr = dop_projections(ld3(ro), ld3(rd));
-    // A candidate is ONE 64-bit word — its sort key in the upper half, its instance slot in the lower — so that an insertion
-    // step is one comparison and two selects per half instead of a comparison per half and an exchange behind a branch.
-    // Closest hit: key = the bits of the entry distance (never negative, so the bit patterns order like the values); equal
-    // distances are ordered by the slot below them, which is the table order the strict '<' of a plain insertion keeps.
-    // Any hit: key falls as the slot grows, so the list is the table from the back.  An empty entry is all ones.
-    unsigned long long entry[kCandMax];
+    float key[kCandMax];
+    uint32_t slot[kCandMax];
 #pragma unroll
-    for (int j = 0; j < kCandMax; ++j) entry[j] = ~0ull;
+    for (int j = 0; j < kCandMax; ++j) { key[j] = kInfF; slot[j] = PT_NO_NODE; }
     const uint32_t n_inst = sc.n_instances;
     bool finite = true;
 #pragma unroll
@@ -465,7 +461,9 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
         if (__ballot(dist < kInfF) == 0ull) continue;  // no ray of this wavefront touches the instance: skip the insertion
         bool grew = false;
         if (dist < kInfF) {
-            unsigned long long cur = (static_cast<unsigned long long>(any_hit ? 0xfffffffeu - k : __float_as_uint(dist)) << 32) | k;
+            // sorted insertion; strict '<' keeps table order among equal distances
+            float ck = any_hit ? -static_cast<float>(k) : dist;
+            uint32_t cs = k;
             // The walk covers entries 0 .. wave_filled (uniform: nothing is stored beyond the longest list of the wavefront).
             // One straight-line copy of the walk per length, chosen by a scalar branch: a loop that is left early makes the
             // compiler move the sixteen list registers around at every way out.
@@ -473,14 +471,17 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
                 constexpr int kSteps = decltype(steps)::value;
 #pragma unroll
                 for (int j = 0; j < kSteps; ++j) {
-                    const bool sw = cur < entry[j];
-                    const unsigned long long t = entry[j];
-                    entry[j] = sw ? cur : t;
-                    cur = sw ? t : cur;
+                    const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
+                    const float tk = key[j];
+                    const uint32_t ts = slot[j];
+                    key[j] = sw ? ck : tk;
+                    slot[j] = sw ? cs : ts;
+                    ck = sw ? tk : ck;
+                    cs = sw ? ts : cs;
                 }
                 // only a lane whose list was the longest fills the entry at wave_filled (lanes that sit this instance out
                 // hold fewer entries than that already)
-                grew = __ballot(static_cast<uint32_t>(entry[kSteps - 1]) != PT_NO_NODE) != 0ull;
+                grew = __ballot(slot[kSteps - 1] != PT_NO_NODE) != 0ull;
             };
             static_assert(kCandMax == 8, "one case per list length");
             switch (wave_filled) {
@@ -496,9 +497,6 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
         }
         if (__ballot(grew) != 0ull) ++wave_filled;
     }
-    uint32_t slot[kCandMax];
-#pragma unroll
-    for (int j = 0; j < kCandMax; ++j) slot[j] = static_cast<uint32_t>(entry[j]);
     // An entry's slot word carries kCandLast when the stored list ends with it, so a list costs no terminator entry and
     // the traversal kernel knows without a read that nothing follows; an empty list is one entry with the slot PT_NO_NODE.
 #pragma unroll
@@ -508,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
             const uint32_t word = slot[j] | (last ? kCandLast : 0u);
             if (j == 0) cand.h1[gid] = 0u;  // "no hit" until the traversal kernel accepts one: a miss then writes nothing
             if (j == 0) cand.first()[gid] = word;  // (the first candidate's distance is never looked at)
-            else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(any_hit ? 0u : static_cast<uint32_t>(entry[j] >> 32), word);
+            else cand.e[static_cast<size_t>(j) * cand.stride + gid] = make_uint2(__float_as_uint(any_hit ? 0.0f : key[j]), word);
         }
     if (COUNT) atomicAdd(&counters->inst_tested, static_cast<unsigned long long>(n_inst));
     if (COUNT && slot[0] == PT_NO_NODE) atomicAdd(&counters->census[1][1], 1ull);  // rays that touch no instance (an empty list)
