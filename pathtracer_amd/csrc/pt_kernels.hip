@@ -469,15 +469,22 @@ __global__ __launch_bounds__(kBlock) void tlas_kernel(SceneDev sc, const float4*
             // compiler move the sixteen list registers around at every way out.
             auto walk = [&](auto steps) {
                 constexpr int kSteps = decltype(steps)::value;
+                // Once the new entry has found its place every later entry moves down by one, whatever its key: asking
+                // "is the carried entry smaller" again would leave it ABOVE an entry of equal distance (two instances whose
+                // bounds share a plane), the pair would swap places at every insertion in front of them, and when the list
+                // is full the one that falls off could be the one with the smaller slot — which the continuation pass,
+                // looking for entries after (distance, slot) of the last stored one, never finds.
+                bool moving = false;
 #pragma unroll
                 for (int j = 0; j < kSteps; ++j) {
-                    const bool sw = (ck < key[j]) || (slot[j] == PT_NO_NODE);
+                    const bool sw = moving || (ck < key[j]) || (slot[j] == PT_NO_NODE);
                     const float tk = key[j];
                     const uint32_t ts = slot[j];
                     key[j] = sw ? ck : tk;
                     slot[j] = sw ? cs : ts;
                     ck = sw ? tk : ck;
                     cs = sw ? ts : cs;
+                    moving = sw;
                 }
                 // only a lane whose list was the longest fills the entry at wave_filled (lanes that sit this instance out
                 // hold fewer entries than that already)

@@ -399,6 +399,35 @@ def sparse_clouds(n_objects: int = 14, tris_per_object: int = 60, seed: int = 5)
     return b.build()
 
 
+def tied_bounds(n_singles: int = 7, tris_per_object: int = 60, seed: int = 8) -> SceneModel:
+    """Two instances whose bounding volumes are IDENTICAL (equal entry distance for every ray) inside ``n_singles`` instances
+    with larger, nested bounds (nearer entry distances), each holding a sparse cloud of small triangles in the inner cube.
+    The tied pair comes first in the instance table (most triangles) and every other instance is sorted in front of it: the
+    case in which a sorted candidate list must keep table order among equal keys while entries move past them."""
+    rng = np.random.default_rng(seed)
+    b = ModelBuilder("tied_bounds")
+    halves = [1.0, 1.0] + [1.05 + 0.05 * k for k in range(n_singles)]
+    for k, half in enumerate(halves):
+        mat = b.add_material(base_color=(0.3 + 0.05 * (k % 10), 0.6, 0.9 - 0.05 * (k % 10), 1), metallic=0.0, roughness=0.6,
+                             double_sided=(k % 3 == 0))
+        n_tris = tris_per_object + 2 * (len(halves) - k)  # falling counts: the table keeps this order
+        c = rng.uniform(-0.8, 0.8, (n_tris, 1, 3))
+        pos = (c + rng.normal(scale=0.1, size=(n_tris, 3, 3))).clip(-0.95, 0.95).reshape(-1, 3).astype(np.float32)
+        e = np.float32(half)
+        pins = np.array([[-e, -e, -e], [-e + 0.01, -e, -e], [-e, -e + 0.01, -e], [e, e, e], [e - 0.01, e, e], [e, e - 0.01, e],
+                         [-e, e, e], [-e + 0.01, e, e], [-e, e - 0.01, e], [e, -e, -e], [e - 0.01, -e, -e], [e, -e + 0.01, -e],
+                         [e, -e, e], [e - 0.01, -e, e], [e, -e + 0.01, e], [-e, e, -e], [-e + 0.01, e, -e], [-e, e - 0.01, -e],
+                         [e, e, -e], [e - 0.01, e, -e], [e, e - 0.01, -e], [-e, -e, e], [-e + 0.01, -e, e], [-e, -e + 0.01, e]], np.float32)
+        pos = np.concatenate([pos, pins])
+        tri = pos.reshape(-1, 3, 3)
+        n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        n = np.repeat(_normalize(n + 1e-12), 3, axis=0).astype(np.float32)
+        mesh = b.add_mesh(pos, n, np.arange(len(pos), dtype=np.uint32), material=mat)
+        b.add_object(mesh, np.eye(4))
+    b.add_camera(Camera((0.0, 0.3, 4.5), (0.0, -0.05, -1.0), (0.0, 1.0, 0.0), np.radians(40.0), 0.1, 100.0))
+    return b.build()
+
+
 def random_soup(seed: int, n_objects: int = 5, tris_per_object: int = 4000, offset: float = 0.0, flat: bool = False) -> SceneModel:
     """Triangle soups under random affine transforms (rotation, non-uniform scale, shear): no structure a builder or a
     node layout could rely on.  ``offset`` moves every mesh far from its object-space origin (large coordinates, small
