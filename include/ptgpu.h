@@ -235,6 +235,15 @@ typedef struct ptgpu_stats {
     uint32_t ragged_end_in_pieces; /* PBR launches whose output streams ended too far apart for the one-piece fix-up (see
                                       PTGPU_OPT_SMALL_STAGING): closed piece by piece, slower, same rays */
     uint64_t leaf_records_read; /* ptgpu_render_counted, scenes whose four-wide leaves are 64-byte records: records fetched (0 otherwise) */
+    uint64_t rays_abandoned;    /* Chains of rays that were cut because they did not advance.  A pass-through ray (alpha != 1,
+                                   src/ray_program.cc:265-271) starts at position - normal * 1e-5 with the interpolated
+                                   normal; where that normal and the triangle's plane disagree about the side the ray came
+                                   from (flipped vertex normals, smooth normals under strong non-uniform scale), the new origin
+                                   is in front of the triangle again and the reference's loop (src/renderer.cc:111-117)
+                                   never ends.  Here a pass-through ray that comes back to the triangle it has just passed a
+                                   second time in a row (each time within 0.01) is the last of its chain; the frame is
+                                   complete except for what those chains would still have added.  0 on every scene whose
+                                   normals agree with its geometry. */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

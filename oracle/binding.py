@@ -25,7 +25,7 @@ MATH_LIBM, MATH_PORTABLE = 0, 1
 class OrcStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("camera_samples", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("triangles_tested", C.c_uint64), ("instances_tested", C.c_uint64),
-                ("instances_entered", C.c_uint64), ("seconds", C.c_double)]
+                ("instances_entered", C.c_uint64), ("seconds", C.c_double), ("chains_cut", C.c_uint64)]
 
 
 class OrcRay(C.Structure):

@@ -413,11 +413,24 @@ struct Programs {
         float alpha = albedo.w;
         if (!mat.alpha_blending) alpha = (alpha < mat.alpha_cutoff) ? 0.0f : 1.0f;
         if (alpha != 1.0f) {  // pass-through ray, :265-271
-            RayP nr = ray;
-            nr.origin = p.position + (exiting ? 1.0f : -1.0f) * p.normal * 1e-5f;
-            nr.payload = nr.payload * (1.0f - alpha);
-            nr.key = rng_child(ray.key, LOBE_PASS);
-            out.push_back(nr);
+            // Not in the reference, shared with the GPU library (ptgpu_stats.rays_abandoned): the new origin is offset along
+            // the INTERPOLATED normal, and where that normal and the triangle's plane disagree about the side the ray came
+            // from the ray hits the same triangle again, for ever, spawning the other lobes every time.  A pass-through ray
+            // carries an 8-bit tag of the triangle it passed and one bit "already a second visit"; the third visit in a row
+            // of one triangle, each closer than 0.01, spawns no pass-through ray.  No scene whose normals agree with its
+            // geometry gets there.
+            const uint32_t h = pass_hash(hit.object, hit.triangle);
+            const bool again = (hit.t < 1e-2f) && ((ray.pass_tag & 0xffu) == h);
+            if (again && (ray.pass_tag >> 8)) {
+                ++chains_cut;
+            } else {
+                RayP nr = ray;
+                nr.origin = p.position + (exiting ? 1.0f : -1.0f) * p.normal * 1e-5f;
+                nr.payload = nr.payload * (1.0f - alpha);
+                nr.key = rng_child(ray.key, LOBE_PASS);
+                nr.pass_tag = (again ? 0x100u : 0u) | h;
+                out.push_back(nr);
+            }
         }
         if (alpha == 0.0f) return V3(0.0f);
 
@@ -549,6 +562,7 @@ struct Programs {
         return radiance;
     }
     bool single_path = false;
+    mutable std::atomic<uint64_t> chains_cut{0};  // pass-through chains that did not advance (see pbr())
     V3 on_hit(int mode, const RayP& ray, const TriHit& hit, std::vector<RayP>& out, Sampler& smp) const {
         switch (mode) {
             case 1: return ao(ray, hit, out, smp);
@@ -624,6 +638,7 @@ int render_rows(orc_scene* s, int W, int H, int y0, int y1, float* out, int n_th
     n_threads = std::min(n_threads, std::max(1, y1 - y0));
 
     std::atomic<int> next_row{y0};
+    s->programs.chains_cut = 0;
     std::vector<Counters> per_thread(n_threads);
     auto t_start = std::chrono::steady_clock::now();
     auto worker = [&](int tid) {
@@ -679,6 +694,7 @@ int render_rows(orc_scene* s, int W, int H, int y0, int y1, float* out, int n_th
         for (uint32_t i = begin; i < spp; i += step) ++per_px;
         r.camera_samples = per_px * static_cast<uint64_t>(W) * static_cast<uint64_t>(y1 - y0);
         r.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        r.chains_cut = s->programs.chains_cut.load();
         *stats = r;
     }
     return 0;

@@ -110,7 +110,7 @@ class Stats(C.Structure):
         ("triangles_tested", C.c_uint64), ("instances_tested", C.c_uint64), ("instances_entered", C.c_uint64),
         ("wave_inner_iterations", C.c_uint64), ("wave_triangle_iterations", C.c_uint64),
         ("traverse_ms", C.c_double), ("nodes_from_lds", C.c_uint64), ("traverse_workgroups_per_cu", C.c_uint32), ("ragged_end_in_pieces", C.c_uint32),
-        ("leaf_records_read", C.c_uint64),
+        ("leaf_records_read", C.c_uint64), ("rays_abandoned", C.c_uint64),
     ]
 
 

@@ -83,6 +83,7 @@ struct CameraDev {
 struct FrameDev {
     float* sum;          // planar R | G | B sums, each `stride` floats, indexed by framebuffer slot
     uint32_t stride;
+    uint32_t* abandoned; // counts pass-through chains that were cut (see pass_hash in pt_kernels.hip); PBR only, else null
 };
 
 struct TraceCounters {   // filled by the counting variant of extend

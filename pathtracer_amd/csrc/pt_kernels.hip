@@ -1427,7 +1427,9 @@ __global__ __launch_bounds__(kBlock) void generate_kernel(CameraDev cam, const f
             o4 = make_float4(cam.origin[0], cam.origin[1], cam.origin[2], __uint_as_float(pid));
             // bits 0-7 bounces left, bit 8 any-hit, bits 9-31 the framebuffer slot again (frames below 2^23 slots): the
             // PBR shade kernel then needs no read of the origin record
-            d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float((max_bounces & 0xffu) | (pid << 9)));
+            // (larger frames keep those bits clear: the PBR kernel keeps a pass-through ray's tag there, see pass_hash)
+            const bool slot_fits = static_cast<uint32_t>(cam.tiles_x) * static_cast<uint32_t>(cam.tiles_y) * 64u < (1u << 23);
+            d4 = make_float4(dir.x, dir.y, dir.z, __uint_as_float((max_bounces & 0xffu) | (slot_fits ? pid << 9 : 0u)));
             p4 = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(rng_camera_key(seed, pixel, sample)));
         }
     }
@@ -1808,6 +1810,20 @@ __device__ __forceinline__ float lobe_weight(f3 p) {
     return ((w > 0.0f) && (w < kInfF)) ? w : 0.0f;
 }
 
+// A pass-through ray (alpha != 1, ray_program.cc:265-271) starts at position -/+ normal * 1e-5 with the INTERPOLATED normal.
+// Where that normal and the triangle's plane disagree about the side the ray came from (flipped vertex normals; smooth normals
+// under strong non-uniform scale at a low angle), the new origin is in front of the triangle again, the ray hits the same
+// triangle again a hair's breadth away, and the reference's loop (renderer.cc:111-117) never ends — with the other lobes
+// spawned at every step.  Here a pass-through ray carries a tag of the triangle it passed: an 8-bit hash of (object,
+// triangle), never 0, and one bit that says "this ray was already a second visit" — in the nine bits above the
+// framebuffer slot of its origin record (frames below 2^23 slots) or above the depth of its direction record (larger
+// frames).  The third visit in a row of one triangle, each closer than kPassNear, spawns no pass-through ray and is counted
+// in FrameDev::abandoned.  (Two different triangles that close with equal hashes, twice in a row: 1.5e-5 per such pair.)
+constexpr float kPassNear = 1e-2f;
+__device__ __forceinline__ uint32_t pass_hash(uint32_t object, uint32_t triangle) {
+    return 1u + mix32(triangle ^ (object * 0x9e3779b9u)) % 255u;
+}
+
 template <bool SINGLE, bool ALL_LDS>
 __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uint32_t n, HitQueue hits,
                                                            RayQueue out, Reservation res, FrameDev fb) {
@@ -1835,9 +1851,11 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
 
     // the framebuffer slot rides in the direction record's flag word when it fits (uniform choice per frame); asked for
     // again in stage C instead of being kept in a register
+    const bool slot_fits = fb.stride < (1u << 23);
     auto slot_of = [&]() -> uint32_t {
-        return (fb.stride < (1u << 23)) ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
+        return slot_fits ? (__float_as_uint(rd.w) >> 9) : __float_as_uint(rays.o[i].w);
     };
+    uint32_t pass_tag = 0;  // of the pass-through ray this hit spawns (see pass_hash)
     if (i < n) {
         rd = rays.d[i];
         const float4 rp = rays.p[i];
@@ -1866,7 +1884,13 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             const float4 albedo = sample_albedo(sc, mat, sp.p.u, sp.p.v);
             alpha = albedo.w;
             if (!mat.alpha_blending) alpha = (alpha < mat.alpha_cutoff) ? 0.0f : 1.0f;
-            has[0] = (alpha != 1.0f);  // pass-through ray: same direction and depth (ray_program.cc:265-271)
+            if (alpha != 1.0f) {  // pass-through ray: same direction and depth (ray_program.cc:265-271)
+                const uint32_t tag = slot_fits ? (__float_as_uint(rays.o[i].w) >> 23) : ((__float_as_uint(rd.w) >> 9) & 0x1ffu);
+                const uint32_t h = pass_hash(h1 & 0x3fffffffu, __float_as_uint(h0.w));
+                const bool again = (h0.x < kPassNear) && ((tag & 0xffu) == h);
+                if (again && (tag >> 8)) atomicAdd(fb.abandoned, 1u);  // third visit in a row: the chain does not advance
+                else pass_tag = (again ? 0x100u : 0u) | h, has[0] = true;
+            }
             if (alpha != 0.0f) {
                 if (exiting) {  // volume absorption on the segment that leaves the volume (:278-279)
                     const f3 e = f3{-mat.attenuation[0], -mat.attenuation[1], -mat.attenuation[2]} * h0.x;
@@ -1917,7 +1941,9 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     const unsigned long long lt = (1ull << lane_id) - 1ull;
     auto store = [&](uint32_t number, f3 org, float4 d4, f3 pl, uint32_t lobe) {
         const uint32_t dst = queue_slot(res, number);
-        out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of()));
+        const bool pass = lobe == LOBE_PASS;
+        out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of() | ((pass && slot_fits) ? pass_tag << 23 : 0u)));
+        if (pass && !slot_fits) d4.w = __uint_as_float((__float_as_uint(d4.w) & 0x1ffu) | (pass_tag << 9));
         out.d[dst] = d4;
         out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
     };
@@ -1928,7 +1954,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const f3 f90 = mk3(1.0f);
         const f3 v = -ld3(rd);
         const f3 l_refr = refract3(-v, m, eta);
-        const uint32_t nflags = (((__float_as_uint(rd.w) & 0xffu) - 1u) & 0xffu) | (slot_of() << 9);
+        const uint32_t nflags = (((__float_as_uint(rd.w) & 0xffu) - 1u) & 0xffu) | (slot_fits ? slot_of() << 9 : 0u);
         if (has[1]) {  // diffuse lobe (:306-323)
             const f3 l = l_diff;
             const f3 h = normalize3(v + l);

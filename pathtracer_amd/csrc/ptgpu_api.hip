@@ -452,7 +452,8 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     if (rc) return rc;
     const uint64_t L = c->launch_cap;
     PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
-    ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride};
+    ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride, c->counter.as<uint32_t>() + 2};  // (word 0 of that buffer is the queue counter)
+    PT_HIP(c, hipMemsetAsync(fb.abandoned, 0, 4, st));
     ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3);  // framebuffer.clear, renderer.cc:85
     const std::vector<float> sub = subsample_table(spp);
     PT_HIP(c, c->subs.ensure(sub.size() * 4));
@@ -612,9 +613,11 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
         ptd::launch_resolve(st, fb, g.cam, d_rgba, mean ? n_samples : 1.0f, mean ? 1.0f : n_samples);
     }
     PT_HIP(c, hipEventRecord(c->ev[5], st));
+    PT_HIP(c, hipMemcpyAsync(c->host_counter + 2, fb.abandoned, 4, hipMemcpyDeviceToHost, st));
     PT_SYNC(c, st);
     PT_HIP(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     out.total_ms = ms;
+    out.rays_abandoned = c->host_counter[2];
     out.traverse_workgroups_per_cu = c->persistent ? (c->scene.nodes4 && c->scene.seven_waves ? 7u : 6u) : 0u;
     if (counted) {
         ptd::TraceCounters tc;

@@ -428,6 +428,21 @@ def tied_bounds(n_singles: int = 7, tris_per_object: int = 60, seed: int = 8) ->
     return b.build()
 
 
+def endless_pass_through() -> SceneModel:
+    """An alpha-blended quad whose vertex normals point AWAY from the side its winding calls the front (an exporter's flipped
+    normals), over a floor.  A ray that hits the front spawns its pass-through ray at position - normal * 1e-5
+    (src/ray_program.cc:265-271) — which, with this normal, is in front of the quad again: the chain never ends and the
+    reference's frame loop never returns."""
+    b = ModelBuilder("endless_pass_through")
+    mat = b.add_material(base_color=(0.8, 0.7, 0.6, 0.5), metallic=0.0, roughness=0.5, alpha_mode="BLEND")
+    pos, nrm, idx, uv, tan = _args(quad(2.0, 2.0))
+    b.add_object(b.add_mesh(pos, -np.asarray(nrm), idx, uv, tan, material=mat))
+    floor = b.add_mesh(*_args(plane(2, 2, 8.0, 8.0)), material=b.add_material(metallic=0.0, roughness=0.8))
+    b.add_object(floor, translate(0.0, -1.5, 0.0))
+    b.add_camera(Camera((0.0, 0.0, 5.0), (0.0, 0.0, -1.0), (0.0, 1.0, 0.0), np.radians(40.0), 0.1, 100.0))
+    return b.build()
+
+
 def random_soup(seed: int, n_objects: int = 5, tris_per_object: int = 4000, offset: float = 0.0, flat: bool = False) -> SceneModel:
     """Triangle soups under random affine transforms (rotation, non-uniform scale, shear): no structure a builder or a
     node layout could rely on.  ``offset`` moves every mesh far from its object-space origin (large coordinates, small

@@ -46,3 +46,34 @@ def test_failed_allocations_leave_a_usable_context():
     finally:
         os.environ.pop("PTGPU_TEST_FAIL_ALLOC", None)
     assert failures >= 6, failures
+
+
+@pytest.mark.gpu
+def test_a_chain_of_rays_that_never_ends_is_abandoned():
+    """The reference's frame loop does not return when a pass-through ray keeps landing in front of the surface it passed
+    (flipped vertex normals under an alpha-blended material; also smooth normals under strong non-uniform scale, at grazing
+    angles).  The library must return: a pass-through ray that comes back to the triangle it has just passed for the second
+    time in a row ends its chain; the cut chains are counted.  The oracle applies the same rule, so everything stays comparable: ray counts, the
+    number of chains, the picture."""
+    model, env = scenes.endless_pass_through(), scenes.synthetic_env()
+    w, h = 24, 16
+    st = H.settings(program=2, spp=1, bounces=2)
+    g = H.make_gpu(model, env, st, w, h)
+    img, s = H.gpu_render(g, w, h)
+    assert s.rays_abandoned > 0 and s.camera_samples == w * h
+    o = H.make_oracle(model, env, st, w, h)
+    img_o, so = o.render_frame(w, h)
+    assert so.chains_cut == s.rays_abandoned and so.rays == s.rays
+    assert np.isfinite(img).all()
+    assert np.abs(img[..., :3] - img_o[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_o[..., :3]).max())
+    single = H.settings(program=2, spp=2, bounces=3, single=True)
+    gs, os_ = H.make_gpu(model, env, single, w, h), H.make_oracle(model, env, single, w, h)
+    (img_s, ss), (img_o, so) = H.gpu_render(gs, w, h), os_.render_frame(w, h)
+    assert so.chains_cut == ss.rays_abandoned and so.rays == ss.rays
+    assert np.abs(img_s[..., :3] - img_o[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_o[..., :3]).max())
+    # the context renders on: the same scene without the offending sample count, then an ordinary frame
+    img2, s2 = H.gpu_render(g, w, h)
+    assert s2.rays_abandoned == s.rays_abandoned
+    ok = H.make_gpu(scenes.tiny_scene(), env, st, w, h)
+    _, s3 = H.gpu_render(ok, w, h)
+    assert s3.rays_abandoned == 0
