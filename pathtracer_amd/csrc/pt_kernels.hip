@@ -1815,13 +1815,15 @@ __device__ __forceinline__ float lobe_weight(f3 p) {
 // under strong non-uniform scale at a low angle), the new origin is in front of the triangle again, the ray hits the same
 // triangle again a hair's breadth away, and the reference's loop (renderer.cc:111-117) never ends — with the other lobes
 // spawned at every step.  Here a pass-through ray carries a tag of the triangle it passed: an 8-bit hash of (object,
-// triangle), never 0, and one bit that says "this ray was already a second visit" — in the nine bits above the
+// triangle), odd and so never 0, and one bit that says "this ray was already a repeated visit" — in the nine bits above the
 // framebuffer slot of its origin record (frames below 2^23 slots) or above the depth of its direction record (larger
-// frames).  The third visit in a row of one triangle, each closer than kPassNear, spawns no pass-through ray and is counted
-// in FrameDev::abandoned.  (Two different triangles that close with equal hashes, twice in a row: 1.5e-5 per such pair.)
+// frames) — and, as the sign of its payload's first component, a mark "my parent's hit was closer than kPassNear": only
+// a marked ray that hits something that close again has its tag looked at, so ordinary frames never pay for the read.
+// Parent far, then the same triangle three times in a row, each closer than kPassNear: the third spawns no pass-through
+// ray and is counted in FrameDev::abandoned.  (Different triangles that close with equal tags — 128 odd values — twice running: 6e-5.)
 constexpr float kPassNear = 1e-2f;
 __device__ __forceinline__ uint32_t pass_hash(uint32_t object, uint32_t triangle) {
-    return 1u + mix32(triangle ^ (object * 0x9e3779b9u)) % 255u;
+    return (((triangle * 0x9e3779b9u) ^ (object * 0x85ebca6bu)) >> 24) | 1u;
 }
 
 template <bool SINGLE, bool ALL_LDS>
@@ -1863,7 +1865,9 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const uint32_t pid = slot_of();
         key = __float_as_uint(rp.w);
         const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
-        payload = f3{rp.x, rp.y, rp.z};
+        // (a payload is never negative: the sign of its first component marks a pass-through ray whose parent hit was close)
+        const bool marked = (__float_as_uint(rp.x) >> 31) != 0u;
+        payload = f3{fabsf(rp.x), rp.y, rp.z};
         const f3 dir = ld3(rd);
         f3 radiance = mk3(0.0f);
         if (!(h1 & 0x80000000u)) {
@@ -1885,11 +1889,13 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             alpha = albedo.w;
             if (!mat.alpha_blending) alpha = (alpha < mat.alpha_cutoff) ? 0.0f : 1.0f;
             if (alpha != 1.0f) {  // pass-through ray: same direction and depth (ray_program.cc:265-271)
-                const uint32_t tag = slot_fits ? (__float_as_uint(rays.o[i].w) >> 23) : ((__float_as_uint(rd.w) >> 9) & 0x1ffu);
                 const uint32_t h = pass_hash(h1 & 0x3fffffffu, __float_as_uint(h0.w));
-                const bool again = (h0.x < kPassNear) && ((tag & 0xffu) == h);
-                if (again && (tag >> 8)) atomicAdd(fb.abandoned, 1u);  // third visit in a row: the chain does not advance
-                else pass_tag = (again ? 0x100u : 0u) | h, has[0] = true;
+                const bool near = h0.x < kPassNear;
+                uint32_t tag = 0;  // (only a ray that is marked has one worth reading: one load in a blue moon)
+                if (near && marked) tag = slot_fits ? (__float_as_uint(rays.o[i].w) >> 23) : ((__float_as_uint(rd.w) >> 9) & 0x1ffu);
+                const bool again = near && marked && ((tag & 0xffu) == h);
+                if (again && (tag >> 8)) atomicAdd(fb.abandoned, 1u);  // the same triangle a third time: the chain does not advance
+                else pass_tag = (near ? 0x200u : 0u) | (again ? 0x100u : 0u) | h, has[0] = true;
             }
             if (alpha != 0.0f) {
                 if (exiting) {  // volume absorption on the segment that leaves the volume (:278-279)
@@ -1942,10 +1948,11 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
     auto store = [&](uint32_t number, f3 org, float4 d4, f3 pl, uint32_t lobe) {
         const uint32_t dst = queue_slot(res, number);
         const bool pass = lobe == LOBE_PASS;
-        out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of() | ((pass && slot_fits) ? pass_tag << 23 : 0u)));
-        if (pass && !slot_fits) d4.w = __uint_as_float((__float_as_uint(d4.w) & 0x1ffu) | (pass_tag << 9));
+        out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of() | ((pass && slot_fits) ? (pass_tag & 0x1ffu) << 23 : 0u)));
+        if (pass && !slot_fits) d4.w = __uint_as_float((__float_as_uint(d4.w) & 0x1ffu) | ((pass_tag & 0x1ffu) << 9));
         out.d[dst] = d4;
-        out.p[dst] = make_float4(pl.x, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
+        const float plx = (pass && (pass_tag & 0x200u)) ? -pl.x : pl.x;  // the mark (see stage A)
+        out.p[dst] = make_float4(plx, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
     };
     // ---- stage C: the lobes; `emit(s, ...)` is called with s = the lobe's number (LOBE_PASS .. LOBE_REFLECT) ----
     auto lobes = [&](auto&& emit) {

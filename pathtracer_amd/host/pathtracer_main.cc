@@ -142,6 +142,8 @@ int main(int argc, char* argv[]) {
                       << " shade_ms " << s.shade_ms << " Mrays/s " << (s.total_ms > 0 ? s.rays / s.total_ms / 1e3 : 0.0) << '\n';
             // (one, however many devices render: the first builds, the others copy its device buffers)
             std::cout << "acceleration structure builds " << ptgpu_host_build_count() << " devices " << args.gpus << '\n';
+            if (s.rays_abandoned)  // (flipped vertex normals under an alpha-blended material, mostly: see ptgpu_stats)
+                std::cout << "pass-through chains cut because they did not advance: " << s.rays_abandoned << '\n';
         }
 
         start = std::chrono::high_resolution_clock::now();
