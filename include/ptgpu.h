@@ -240,10 +240,10 @@ typedef struct ptgpu_stats {
                                    normal; where that normal and the triangle's plane disagree about the side the ray came
                                    from (flipped vertex normals, smooth normals under strong non-uniform scale), the new origin
                                    is in front of the triangle again and the reference's loop (src/renderer.cc:111-117)
-                                   never ends.  Here a pass-through ray that comes back to the triangle it has just passed a
-                                   second time in a row (each time within 0.01) is the last of its chain; the frame is
-                                   complete except for what those chains would still have added.  0 on every scene whose
-                                   normals agree with its geometry. */
+                                   never ends.  Here a chain of pass-through rays ends at the third visit in a row of one
+                                   triangle, each within 0.001 of the last, and in any case at the eighth such step in a
+                                   row; the frame is complete except for what those chains would still have added.  0 on
+                                   every scene whose normals agree with its geometry. */
 } ptgpu_stats;
 
 typedef struct ptgpu_bvh_info {

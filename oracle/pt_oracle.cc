@@ -416,22 +416,22 @@ struct Programs {
             // Not in the reference, shared with the GPU library (ptgpu_stats.rays_abandoned): the new origin is offset along
             // the INTERPOLATED normal, and where that normal and the triangle's plane disagree about the side the ray came
             // from the ray hits the same triangle again, for ever, spawning the other lobes every time.  A pass-through ray
-            // carries an 8-bit tag of the triangle it passed, one bit "my parent's hit was closer than 0.01" and one bit
-            // "already a repeated visit"; after a first hit, the third visit in a row of the same triangle, each that close,
-            // spawns no pass-through ray.  No scene whose normals agree with its
-            // geometry gets there.
+            // carries the number (0..7) of pass-through steps in a row that ended closer than 0.001, a 5-bit tag of the
+            // triangle it passed and one bit "already a repeated visit".  The chain ends at the third visit in a row of one
+            // triangle, and in any case at the eighth close step in a row (a ray on an edge may alternate between the
+            // triangles that share it).  No scene whose normals agree with its geometry gets there.
             const uint32_t h = pass_hash(hit.object, hit.triangle);
-            const bool near = hit.t < 1e-2f;
-            const bool marked = (ray.pass_tag & 0x200u) != 0;  // the parent's hit was that close too
-            const bool again = near && marked && ((ray.pass_tag & 0xffu) == h);
-            if (again && (ray.pass_tag & 0x100u)) {
+            const uint32_t close_steps = ray.pass_tag >> 9;
+            const bool near = hit.t < 1e-3f;
+            const bool again = near && close_steps && ((ray.pass_tag & 0xffu) == h);
+            if (near && ((again && (ray.pass_tag & 0x100u)) || close_steps >= 7u)) {
                 ++chains_cut;
             } else {
                 RayP nr = ray;
                 nr.origin = p.position + (exiting ? 1.0f : -1.0f) * p.normal * 1e-5f;
                 nr.payload = nr.payload * (1.0f - alpha);
                 nr.key = rng_child(ray.key, LOBE_PASS);
-                nr.pass_tag = (near ? 0x200u : 0u) | (again ? 0x100u : 0u) | h;
+                nr.pass_tag = ((near ? close_steps + 1u : 0u) << 9) | (again ? 0x100u : 0u) | h;
                 out.push_back(nr);
             }
         }

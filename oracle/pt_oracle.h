@@ -121,7 +121,7 @@ typedef struct orc_stats {
     uint64_t instances_tested;  /* DOP tests */
     uint64_t instances_entered; /* mesh traversals started */
     double seconds;
-    uint64_t chains_cut;        /* pass-through chains cut at the third visit in a row of one triangle: the rule the GPU
+    uint64_t chains_cut;        /* pass-through chains cut at the third visit in a row of one triangle or the eighth close step: the rule the GPU
                                    library counts in ptgpu_stats.rays_abandoned (the reference would not return) */
 } orc_stats;
 

@@ -307,8 +307,8 @@ inline float rng_uniform(uint32_t key, uint32_t j) {
 }
 inline uint32_t rng_child(uint32_t key, uint32_t lobe) { return mix32((key ^ 0x68bc21ebU) + (lobe + 1u) * 0x02e5be93U); }
 enum { LOBE_PASS = 0, LOBE_DIFFUSE = 1, LOBE_TRANSMIT = 2, LOBE_REFLECT = 3, LOBE_AO0 = 4 };
-// 8-bit tag of a triangle, never 0 (same definition as the GPU library's pass_hash)
-inline uint32_t pass_hash(uint32_t object, uint32_t triangle) { return (((triangle * 0x9e3779b9U) ^ (object * 0x85ebca6bU)) >> 24) | 1u; }
+// 5-bit tag of a triangle (same definition as the GPU library's pass_hash)
+inline uint32_t pass_hash(uint32_t object, uint32_t triangle) { return ((triangle * 0x9e3779b9U) ^ (object * 0x85ebca6bU)) >> 27; }
 
 // ------------------------------------------------------------------------------------------
 // textures (src/cpu_framebuffer.h:14-59, 90-123)

@@ -1812,18 +1812,21 @@ __device__ __forceinline__ float lobe_weight(f3 p) {
 
 // A pass-through ray (alpha != 1, ray_program.cc:265-271) starts at position -/+ normal * 1e-5 with the INTERPOLATED normal.
 // Where that normal and the triangle's plane disagree about the side the ray came from (flipped vertex normals; smooth normals
-// under strong non-uniform scale at a low angle), the new origin is in front of the triangle again, the ray hits the same
-// triangle again a hair's breadth away, and the reference's loop (renderer.cc:111-117) never ends — with the other lobes
-// spawned at every step.  Here a pass-through ray carries a tag of the triangle it passed: an 8-bit hash of (object,
-// triangle), odd and so never 0, and one bit that says "this ray was already a repeated visit" — in the nine bits above the
-// framebuffer slot of its origin record (frames below 2^23 slots) or above the depth of its direction record (larger
-// frames) — and, as the sign of its payload's first component, a mark "my parent's hit was closer than kPassNear": only
-// a marked ray that hits something that close again has its tag looked at, so ordinary frames never pay for the read.
-// Parent far, then the same triangle three times in a row, each closer than kPassNear: the third spawns no pass-through
-// ray and is counted in FrameDev::abandoned.  (Different triangles that close with equal tags — 128 odd values — twice running: 6e-5.)
-constexpr float kPassNear = 1e-2f;
+// under strong non-uniform scale at a low angle; coordinates so large that the offset vanishes), the new origin is in front
+// of the triangle again, the ray hits it again a hair's breadth away, and the reference's loop (renderer.cc:111-117) never
+// ends — with the other lobes spawned at every step.  Here a pass-through ray carries, in the nine bits above the framebuffer
+// slot of its origin record (frames below 2^23 slots) or above the depth of its direction record (larger frames): a 5-bit
+// tag of the triangle it passed, the number (1..7) of pass-through steps in a row that ended closer than kPassNear, and one
+// bit "this ray was already a repeated visit"; and, as the sign of its payload's first component (never negative otherwise),
+// a mark "that number is not 0".  Only a marked ray whose hit is that close again reads the nine bits, so ordinary frames
+// never pay for them.  A chain ends — no pass-through ray, one more in FrameDev::abandoned — at the third visit in a row of one
+// triangle (the common case, cut early because every step spawns its lobes), and in any case at the eighth close step in a
+// row (a ray on an edge may alternate between the triangles that share it).  Eight real layers less than kPassNear apart
+// leave nothing of a payload worth following; different triangles that close with equal tags twice running: 1e-3.
+constexpr float kPassNear = 1e-3f;
+constexpr uint32_t kPassSteps = 7u;
 __device__ __forceinline__ uint32_t pass_hash(uint32_t object, uint32_t triangle) {
-    return (((triangle * 0x9e3779b9u) ^ (object * 0x85ebca6bu)) >> 24) | 1u;
+    return ((triangle * 0x9e3779b9u) ^ (object * 0x85ebca6bu)) >> 27;
 }
 
 template <bool SINGLE, bool ALL_LDS>
@@ -1865,7 +1868,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const uint32_t pid = slot_of();
         key = __float_as_uint(rp.w);
         const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
-        // (a payload is never negative: the sign of its first component marks a pass-through ray whose parent hit was close)
+        // (a payload is never negative: the sign of its first component marks a pass-through ray spawned at a close hit, see kPassNear)
         const bool marked = (__float_as_uint(rp.x) >> 31) != 0u;
         payload = f3{fabsf(rp.x), rp.y, rp.z};
         const f3 dir = ld3(rd);
@@ -1891,11 +1894,12 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
             if (alpha != 1.0f) {  // pass-through ray: same direction and depth (ray_program.cc:265-271)
                 const uint32_t h = pass_hash(h1 & 0x3fffffffu, __float_as_uint(h0.w));
                 const bool near = h0.x < kPassNear;
-                uint32_t tag = 0;  // (only a ray that is marked has one worth reading: one load in a blue moon)
+                uint32_t tag = 0;  // (read once in a blue moon)
                 if (near && marked) tag = slot_fits ? (__float_as_uint(rays.o[i].w) >> 23) : ((__float_as_uint(rd.w) >> 9) & 0x1ffu);
-                const bool again = near && marked && ((tag & 0xffu) == h);
-                if (again && (tag >> 8)) atomicAdd(fb.abandoned, 1u);  // the same triangle a third time: the chain does not advance
-                else pass_tag = (near ? 0x200u : 0u) | (again ? 0x100u : 0u) | h, has[0] = true;
+                const uint32_t close_steps = (tag >> 5) & 7u;  // (0 for a ray that is not marked)
+                const bool again = near && marked && ((tag & 0x1fu) == h);
+                if (near && ((again && (tag >> 8)) || close_steps >= kPassSteps)) atomicAdd(fb.abandoned, 1u);  // the chain does not advance
+                else pass_tag = (again ? 0x100u : 0u) | ((near ? close_steps + 1u : 0u) << 5) | h, has[0] = true;
             }
             if (alpha != 0.0f) {
                 if (exiting) {  // volume absorption on the segment that leaves the volume (:278-279)
@@ -1951,7 +1955,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         out.o[dst] = make_float4(org.x, org.y, org.z, __uint_as_float(slot_of() | ((pass && slot_fits) ? (pass_tag & 0x1ffu) << 23 : 0u)));
         if (pass && !slot_fits) d4.w = __uint_as_float((__float_as_uint(d4.w) & 0x1ffu) | ((pass_tag & 0x1ffu) << 9));
         out.d[dst] = d4;
-        const float plx = (pass && (pass_tag & 0x200u)) ? -pl.x : pl.x;  // the mark (see stage A)
+        const float plx = (pass && (pass_tag & 0xe0u)) ? -pl.x : pl.x;  // the mark: spawned at a close hit (see stage A)
         out.p[dst] = make_float4(plx, pl.y, pl.z, __uint_as_float(rng_child(key, lobe)));
     };
     // ---- stage C: the lobes; `emit(s, ...)` is called with s = the lobe's number (LOBE_PASS .. LOBE_REFLECT) ----

@@ -71,6 +71,14 @@ def test_a_chain_of_rays_that_never_ends_is_abandoned():
     (img_s, ss), (img_o, so) = H.gpu_render(gs, w, h), os_.render_frame(w, h)
     assert so.chains_cut == ss.rays_abandoned and so.rays == ss.rays
     assert np.abs(img_s[..., :3] - img_o[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_o[..., :3]).max())
+    # frames beyond 2^23 framebuffer slots keep the tag in the direction record instead of the origin record
+    big = H.settings(program=2, spp=1, bounces=1)
+    W, Hh = 4096, 2056
+    gb, ob = H.make_gpu(model, env, big, W, Hh), H.make_oracle(model, env, big, W, Hh)
+    (img_b, sb), (img_ob, sob) = H.gpu_render(gb, W, Hh), ob.render_frame(W, Hh)
+    assert sob.chains_cut == sb.rays_abandoned > 0 and sob.rays == sb.rays
+    assert np.abs(img_b[..., :3] - img_ob[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_ob[..., :3]).max())
+    del gb, ob
     # the context renders on: the same scene without the offending sample count, then an ordinary frame
     img2, s2 = H.gpu_render(g, w, h)
     assert s2.rays_abandoned == s.rays_abandoned

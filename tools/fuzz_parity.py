@@ -208,6 +208,18 @@ def one_zoo_seed(seed: int) -> list[str]:
             if bad.sum() > allowed or flag_diff > allowed:
                 fails.append(f"{name} hits wide={wide}: {int(bad.sum())} differ beyond ties, {flag_diff} hit flags differ")
         del g
+    # the entry point that allocates nothing, on device pointers: the records of the allocating one
+    import torch
+    g = H.make_gpu(model, None, H.settings(program=0, leaf=leaf, wide=bool(rng.integers(0, 2))), w, h)
+    m = int(rng.integers(1, min(n, abi.STATIC_MAX_RAYS)))
+    d_o, d_d, d_f = (torch.from_numpy(a[:m].copy()).cuda() for a in (org, d, flags))
+    d_out = torch.zeros(m * abi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    g.intersect_rays_static(m, d_o.data_ptr(), d_d.data_ptr(), d_f.data_ptr(), d_out.data_ptr())
+    got_static = d_out.cpu().numpy().view(abi.HIT_DTYPE)
+    exact, _ = H.hits_equal(g.intersect_rays(org[:m], d[:m], flags[:m]), got_static)
+    if not exact.all():
+        fails.append(f"static entry point: {int((~exact).sum())} of {m} records differ from ptgpu_intersect_rays")
+    del g
     program = int(rng.choice([0, 1, 2, 2, 2]))
     single = bool(rng.integers(0, 2)) and program == 2
     bounces = int(rng.choice([1, 2, 3, 4] if not single else [2, 5, 9, 14]))
