@@ -250,6 +250,19 @@ def one_zoo_seed(seed: int) -> list[str]:
         fails.append(f"frame program={program} {fw}x{fh} spp={spp} b={bounces} r={newrays} single={single} samples {begin}+{step}k "
                      f"rot={rot:.2f} {opts}: rays {sg.rays} vs {so.rays}, {int(bad.sum())} pixels off, {int(nan_mismatch.sum())} NaN mismatches, "
                      f"chains cut {sg.rays_abandoned} vs {so.chains_cut}")
+    # the same frame over another tree / the four-wide nodes: another visiting order, so ties and edge hits may fall the other
+    # way and (ambient occlusion beyond one bounce) any-hit chains continue from other points — everything else must agree
+    if not (program == 1 and bounces >= 2) and so.rays < 3_000_000:
+        as_type, wide = int(rng.choice([1, 2])), bool(rng.integers(0, 2))
+        if as_type == 2 or wide:
+            st2 = H.settings(program=program, spp=spp, bounces=bounces, newrays=newrays, single=single, leaf=leaf, seed=seed, begin=begin,
+                             step=step, env_rot=rot, as_type=as_type, wide=wide)
+            g2 = H.make_gpu(model, env, st2, fw, fh)
+            img_2, s2 = H.gpu_render(g2, fw, fh)
+            bad2 = (np.abs(img_2[..., :3] - img_o[..., :3]) > tol * np.maximum(1.0, np.abs(img_o[..., :3]))).any(axis=-1)
+            if abs(int(s2.rays) - int(so.rays)) > max(16, 1e-4 * so.rays) or bad2.sum() > max(2, 2e-3 * fw * fh):
+                fails.append(f"frame as={as_type} wide={wide} program={program} {fw}x{fh} spp={spp} b={bounces} single={single}: rays {s2.rays} vs "
+                             f"{so.rays}, {int(bad2.sum())} pixels off")
     return [f"zoo seed {seed} ({n_obj} objects, leaf {leaf}): {f}" for f in fails]
 
 
