@@ -441,7 +441,9 @@ void build_instances(const ptgpu_model& model, InstanceTable& out) {
         ptd::DevInstance inst;
         ptd::DevXform xf;
         uint32_t complexity;
+        bool hidden;
     };
+    constexpr float kMaxMatrixEntry = 1e18f;  // (what validate_model asks of a model matrix)
     std::vector<Entry> entries(model.n_objects);
     for (uint32_t i = 0; i < model.n_objects; ++i) {
         const ptgpu_object& o = model.objects[i];
@@ -475,6 +477,12 @@ void build_instances(const ptgpu_model& model, InstanceTable& out) {
         e.xf.object_index = i;
         e.xf.mesh_index = o.mesh_index;
         e.complexity = m.n_indices;
+        // A model matrix that cannot be inverted (an object scaled to nothing, the usual way of hiding one) comes with a
+        // normal matrix of infinities and NaNs.  The reference keeps such an object and never hits it: every box test of a
+        // ray taken through that matrix compares NaNs and fails.  Here it is left out of the instance table — the same
+        // picture without the visit — but still counts for the scene's bounds.
+        for (int k = 0; k < 16; ++k)
+            if (!(std::fabs(N[k]) <= kMaxMatrixEntry)) e.hidden = true;
     }
     std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.complexity > b.complexity; });
     out.instances.clear();
@@ -485,8 +493,10 @@ void build_instances(const ptgpu_model& model, InstanceTable& out) {
         dop[2 * a + 1] = kLowest;
     }
     for (const Entry& e : entries) {
-        out.instances.push_back(e.inst);
-        out.xforms.push_back(e.xf);
+        if (!e.hidden) {
+            out.instances.push_back(e.inst);
+            out.xforms.push_back(e.xf);
+        }
         for (int a = 0; a < 7; ++a) {
             dop[2 * a] = std::min(dop[2 * a], e.inst.dop[2 * a]);
             dop[2 * a + 1] = std::max(dop[2 * a + 1], e.inst.dop[2 * a + 1]);

@@ -114,8 +114,15 @@ class SceneModel:
 
 
 def _normal_matrix(m: np.ndarray) -> np.ndarray:
-    """``transpose(inverse(M))`` (``src/model_loader.cc:199``)."""
-    return np.linalg.inv(m.astype(np.float64)).T
+    """``transpose(inverse(M))`` (``src/model_loader.cc:199``).  A matrix without an inverse (an object scaled to nothing)
+    gives what glm's cofactor formula gives: every entry divided by a zero determinant, infinities and NaNs."""
+    m = m.astype(np.float64)
+    try:
+        return np.linalg.inv(m).T
+    except np.linalg.LinAlgError:
+        with np.errstate(all="ignore"):
+            cof = np.array([[(-1.0) ** (r + c) * np.linalg.det(np.delete(np.delete(m, r, 0), c, 1)) for c in range(4)] for r in range(4)])
+            return cof / np.float64(0.0)
 
 
 class ModelBuilder:

@@ -85,3 +85,34 @@ def test_a_chain_of_rays_that_never_ends_is_abandoned():
     ok = H.make_gpu(scenes.tiny_scene(), env, st, w, h)
     _, s3 = H.gpu_render(ok, w, h)
     assert s3.rays_abandoned == 0
+
+
+def test_an_object_scaled_to_nothing_is_left_out():
+    """A node scaled to zero — the usual way of hiding an object in an exported scene — has a model matrix without an inverse
+    and a normal matrix of infinities and NaNs.  The reference keeps such an object and never hits it (every box test of a
+    ray taken through that matrix compares NaNs); the library must load the scene and show the same picture: hit records and
+    frames equal to the oracle's, which restates the reference — also when NOTHING else is in the scene."""
+    from pathtracer_amd.model import Camera, ModelBuilder, scale, translate
+    env = scenes.synthetic_env()
+    for others in (True, False):
+        b = ModelBuilder("hidden")
+        mat = b.add_material(base_color=(0.8, 0.3, 0.2, 1.0), metallic=0.0, roughness=0.5)
+        ball = b.add_mesh(*scenes._args(scenes.uv_sphere(12, 24, 1.0)), material=mat)
+        if others:
+            b.add_object(ball, translate(-1.2, 0.0, 0.0))
+            b.add_object(b.add_mesh(*scenes._args(scenes.plane(2, 2, 8.0, 8.0)), material=mat), translate(0.0, -1.0, 0.0))
+        b.add_object(ball, translate(1.0, 0.5, 0.0) @ scale(0.0))           # a point
+        b.add_object(ball, translate(0.0, 0.5, 1.0) @ scale(1.0, 0.0, 1.0))  # a disc
+        b.add_camera(Camera((0.0, 1.0, 6.0), (0.0, -0.1, -1.0), (0.0, 1.0, 0.0), np.radians(45.0), 0.1, 100.0))
+        model = b.build()
+        assert not np.isfinite(model.objects["normal_matrix"][-1]).all()
+        w, h = 96, 54
+        for wide in (False, True):
+            st = H.settings(program=2, spp=2, bounces=3, wide=wide)
+            g, o = H.make_gpu(model, env, st, w, h), H.make_oracle(model, env, H.settings(program=2, spp=2, bounces=3), w, h)
+            exact, _ = H.hits_equal(o.render_hits(w, h), g.render_hits(w, h))
+            assert exact.all(), (others, wide, int((~exact).sum()))
+            (img, s), (img_o, so) = H.gpu_render(g, w, h), o.render_frame(w, h)
+            assert s.rays == so.rays
+            assert np.abs(img[..., :3] - img_o[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_o[..., :3]).max())
+            assert ((g.get_scene_bound()[0] == o.get_scene_bound()[0]).all() and (g.get_scene_bound()[1] == o.get_scene_bound()[1]).all())

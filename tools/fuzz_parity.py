@@ -169,6 +169,8 @@ def zoo_scene(seed: int):
         sc = rng.uniform(0.3, 1.4, 3) * (0.5 if n_obj >= 40 else 1.0)
         if rng.uniform() < 0.15:
             sc[int(rng.integers(0, 3))] *= -1.0  # a mirror
+        if rng.uniform() < 0.05:
+            sc[int(rng.integers(0, 3))] = 0.0  # scaled to nothing: no inverse, never hit
         m = translate(*rng.uniform(-spread, spread, 3)) @ rotate(rng.normal(size=3), float(rng.uniform(0, 360))) @ scale(*sc)
         b.add_object(int(rng.choice(meshes)), m)
     eye = np.array([rng.uniform(-1, 1), rng.uniform(0, 2), 7.0 if n_obj < 40 else 14.0])
