@@ -132,7 +132,8 @@ struct SceneDev {
     const uint32_t* texels;       // RGBA8
     const float4* env;
     const float* srgb_lut;        // 256 entries: srgb_to_linear(i / 255)
-    uint32_t n_instances;
+    uint32_t n_instances;         // entries of `instances` / `xforms` (objects whose model matrix has no inverse are left out)
+    uint32_t n_objects;           // entries of `objects` (every object of the model: an instance names its object by index)
     uint32_t n_top_nodes;         // nodes[0 .. n_top_nodes) are the most visited ones (kept in LDS by the traversal kernel)
     const TlasNode* tlas;         // threaded tree over the instances' boxes, or null: few instances, every ray tests them all
     uint32_t n_tlas;              // its node count

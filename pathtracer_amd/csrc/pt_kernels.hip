@@ -1496,7 +1496,7 @@ __device__ __forceinline__ void stage_decode_tables(const SceneDev& sc) {
         s_srgb_lut[threadIdx.x] = sc.srgb_lut[threadIdx.x];
         s_unorm_lut[threadIdx.x] = static_cast<float>(threadIdx.x) / 255.0f;
     }
-    const uint32_t n_quarters = (sc.n_instances < kObjLds ? sc.n_instances : kObjLds) * (sizeof(DevObject) / 16);
+    const uint32_t n_quarters = (sc.n_objects < kObjLds ? sc.n_objects : kObjLds) * (sizeof(DevObject) / 16);
     for (uint32_t q = threadIdx.x; q < n_quarters; q += blockDim.x) s_objects[q] = reinterpret_cast<const float4*>(sc.objects)[q];
     __syncthreads();
 }
@@ -2247,7 +2247,7 @@ void launch_shade(hipStream_t st, int program, const SceneDev& sc, RayQueue rays
                   uint32_t* out_count, FrameDev fb, uint32_t ao_samples, bool single_path, const ShadeStreams* streams) {
     if (!n) return;
     const dim3 grid(blocks_for(n)), block(kBlock);
-    const bool all_lds = sc.n_instances <= kObjLds;  // every object record is in the kernel's LDS copy
+    const bool all_lds = sc.n_objects <= kObjLds;  // every object record is in the kernel's LDS copy
     if (program == 1) {
         if (all_lds) PT_LAUNCH(shade_ao_kernel<true>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);
         else PT_LAUNCH(shade_ao_kernel<false>, grid, block, 0, st, sc, rays, n, hits, out, out_count, fb, ao_samples);

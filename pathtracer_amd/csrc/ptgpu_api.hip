@@ -820,6 +820,7 @@ static int upload_built_scene(ptgpu_ctx* c, const pth::BuiltScene& b, const ptgp
 
     ptd::SceneDev& sc = c->scene;
     sc.n_instances = static_cast<uint32_t>(b.instances.size());
+    sc.n_objects = static_cast<uint32_t>(b.objects.size());
     sc.n_top_nodes = b.n_top;
     sc.n_tlas = static_cast<uint32_t>(b.tlas.size());
     sc.n_top_nodes4 = b.n_top4;

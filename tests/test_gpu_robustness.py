@@ -98,14 +98,17 @@ def test_an_object_scaled_to_nothing_is_left_out():
         b = ModelBuilder("hidden")
         mat = b.add_material(base_color=(0.8, 0.3, 0.2, 1.0), metallic=0.0, roughness=0.5)
         ball = b.add_mesh(*scenes._args(scenes.uv_sphere(12, 24, 1.0)), material=mat)
+        # (hidden objects FIRST: the objects that are drawn then have indices beyond the number of instances)
+        b.add_object(ball, translate(1.0, 0.5, 0.0) @ scale(0.0))           # a point
+        b.add_object(ball, translate(0.0, 0.5, 1.0) @ scale(1.0, 0.0, 1.0))  # a disc
         if others:
             b.add_object(ball, translate(-1.2, 0.0, 0.0))
             b.add_object(b.add_mesh(*scenes._args(scenes.plane(2, 2, 8.0, 8.0)), material=mat), translate(0.0, -1.0, 0.0))
-        b.add_object(ball, translate(1.0, 0.5, 0.0) @ scale(0.0))           # a point
-        b.add_object(ball, translate(0.0, 0.5, 1.0) @ scale(1.0, 0.0, 1.0))  # a disc
+            b.add_object(ball, translate(0.3, 0.2, -1.0) @ scale(1.0, 1.0, 0.0))  # another disc, in between
+            b.add_object(ball, translate(1.6, 0.0, 0.5) @ scale(0.6))
         b.add_camera(Camera((0.0, 1.0, 6.0), (0.0, -0.1, -1.0), (0.0, 1.0, 0.0), np.radians(45.0), 0.1, 100.0))
         model = b.build()
-        assert not np.isfinite(model.objects["normal_matrix"][-1]).all()
+        assert not np.isfinite(model.objects["normal_matrix"][0]).all()
         w, h = 96, 54
         for wide in (False, True):
             st = H.settings(program=2, spp=2, bounces=3, wide=wide)
