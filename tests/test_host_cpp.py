@@ -199,3 +199,20 @@ def test_cli_renders_glb_like_the_scene_container(tmp_path):
         outs[ext] = image_io.load_hdr(str(out))[..., :3]
     diff = np.abs(outs["glb"] - outs["ptsc"])
     assert diff.mean() < 2e-3 * max(1.0, outs["ptsc"].mean()) and np.median(diff) == 0.0
+    # a node scaled to nothing (an exporter's way of hiding an object: no inverse, a normal matrix of infinities and NaNs):
+    # the scene must load through both readers and look as if the object were not there
+    import copy
+    hidden = copy.deepcopy(model)
+    extra = hidden.objects[:1].copy()
+    extra["model_matrix"][0] = np.diag([0.0, 0.0, 0.0, 1.0]).astype(np.float32).T.reshape(-1)
+    extra["normal_matrix"][0] = np.nan
+    hidden.objects = np.concatenate([extra, hidden.objects])
+    hidden.save(str(tmp_path / "h.ptsc"))
+    gltf_export.save_glb(hidden, str(tmp_path / "h.glb"))
+    for ext in ("ptsc", "glb"):
+        out = tmp_path / f"h_{ext}.hdr"
+        r = run("-f", tmp_path / f"h.{ext}", "-p", 3, "-a", 2, "-s", 8, "-b", 3, "--width", 64, "--height", 40, "--seed", 5, "-o", out)
+        assert r.returncode == 0, r.stderr
+        got = image_io.load_hdr(str(out))[..., :3]
+        d = np.abs(got - outs[ext])
+        assert d.mean() < 2e-3 * max(1.0, outs[ext].mean()) and np.median(d) == 0.0
