@@ -137,9 +137,10 @@ def zoo_scene(seed: int):
     from pathtracer_amd.model import Camera, ModelBuilder, rotate, scale, translate
     rng = np.random.default_rng(50000 + seed)
     b = ModelBuilder(f"zoo_{seed}")
-    imgs = [b.add_image(scenes.checker_texture(32, 4, seed=seed)), b.add_image(scenes.orm_texture(32, seed=seed)),
-            b.add_image(scenes.bump_normal_map(32)), b.add_image(scenes.alpha_gradient_texture(32)),
-            b.add_image(scenes.leaf_mask_texture(32, seed=seed)), b.add_image(scenes.eyes_emissive_texture(32))]
+    n_tex = int(rng.choice([32, 32, 24, 37, 8]))  # (sizes that are not powers of two wrap by division)
+    imgs = [b.add_image(scenes.checker_texture(n_tex, 4, seed=seed)), b.add_image(scenes.orm_texture(n_tex, seed=seed)),
+            b.add_image(scenes.bump_normal_map(n_tex)), b.add_image(scenes.alpha_gradient_texture(n_tex)),
+            b.add_image(scenes.leaf_mask_texture(n_tex, seed=seed)), b.add_image(scenes.eyes_emissive_texture(n_tex))]
 
     def tex(p=0.4):
         return int(rng.choice(imgs)) if rng.uniform() < p else -1
@@ -161,7 +162,13 @@ def zoo_scene(seed: int):
               lambda: scenes.quad(1.5, 1.0), lambda: scenes.uv_sphere(int(rng.integers(4, 14)), int(rng.integers(6, 20)), 1.0),
               lambda: scenes.blob(int(rng.integers(6, 24)), int(rng.integers(6, 24)), 1.0, 0.2, seed=seed),
               lambda: scenes.torus(int(rng.integers(6, 20)), int(rng.integers(4, 12)), 0.8, 0.3), lambda: scenes.box(1.0, 0.7, 0.5)]
-    meshes = [b.add_mesh(*scenes._args(makers[int(rng.integers(0, len(makers)))]()), material=int(rng.choice(mats + [-1])) if rng.uniform() < 0.9 else None)
+    def shape():
+        pos, nrm, idx, uv, tan = scenes._args(makers[int(rng.integers(0, len(makers)))]())
+        if rng.uniform() < 0.4:  # texture coordinates far outside the unit square, mirrored, off the texel grid
+            uv = np.asarray(uv, np.float64) * float(rng.choice([-2.5, 3.0, 37.7, 0.013])) + rng.uniform(-5.0, 5.0, 2)
+        return pos, nrm, idx, uv, tan
+
+    meshes = [b.add_mesh(*shape(), material=int(rng.choice(mats + [-1])) if rng.uniform() < 0.9 else None)
               for _ in range(int(rng.integers(1, 7)))]
     n_obj = int(rng.choice([1, 2, 5, 9, 14, 30, 120, 250]))
     spread = 2.5 if n_obj < 40 else 6.0
