@@ -272,6 +272,26 @@ def one_zoo_seed(seed: int) -> list[str]:
             if abs(int(s2.rays) - int(so.rays)) > max(16, 1e-4 * so.rays) or bad2.sum() > max(2, 2e-3 * fw * fh):
                 fails.append(f"frame as={as_type} wide={wide} program={program} {fw}x{fh} spp={spp} b={bounces} single={single}: rays {s2.rays} vs "
                              f"{so.rays}, {int(bad2.sum())} pixels off")
+    # the multi-GPU split on one GPU: the partial sums of three ranks' sample subsets, or tile subsets, add up to the frame
+    if step == 1 and so.rays < 1_500_000:
+        from pathtracer_amd.distributed import subset_settings, subset_tiles
+        split = subset_tiles if rng.integers(0, 2) else subset_settings
+        world = int(rng.choice([2, 3, 5]))
+        total = torch.zeros((fh, fw, 4), dtype=torch.float32, device="cuda")
+        rays = 0
+        for rank in range(world):
+            gr = H.make_gpu(model, env, split(st, rank, world), fw, fh)
+            part = torch.zeros((fh, fw, 4), dtype=torch.float32, device="cuda")
+            rays += gr.render_frame_sums(fw, fh, part.data_ptr()).rays
+            torch.cuda.synchronize()
+            total += part
+            del gr
+        g.resolve_sums(fw, fh, total.data_ptr(), spp)
+        torch.cuda.synchronize()
+        img_s = total.cpu().numpy()
+        bad3 = (np.abs(img_s[..., :3] - img_o[..., :3]) > tol * np.maximum(1.0, np.abs(img_o[..., :3]))).any(axis=-1)
+        if rays != sg.rays or bad3.sum() > few_pixels:
+            fails.append(f"{split.__name__} x{world}: rays {rays} vs {sg.rays}, {int(bad3.sum())} pixels off the oracle's frame")
     return [f"zoo seed {seed} ({n_obj} objects, leaf {leaf}): {f}" for f in fails]
 
 
