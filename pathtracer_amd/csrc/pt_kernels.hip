@@ -1868,7 +1868,8 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const uint32_t pid = slot_of();
         key = __float_as_uint(rp.w);
         const uint32_t depth = __float_as_uint(rd.w) & 0xffu;
-        // (a payload is never negative: the sign of its first component marks a pass-through ray spawned at a close hit, see kPassNear)
+        // (a payload is never negative while base colours, alpha and F0 stay within glTF's [0, 1]: the sign of its first component
+        // marks a pass-through ray spawned at a close hit, see kPassNear)
         const bool marked = (__float_as_uint(rp.x) >> 31) != 0u;
         payload = f3{fabsf(rp.x), rp.y, rp.z};
         const f3 dir = ld3(rd);
