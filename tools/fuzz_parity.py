@@ -116,6 +116,14 @@ def one_seed(seed: int) -> list[str]:
     img_g, sg = H.gpu_render(g, fw, fh)
     img_o, so = oo.render_frame(fw, fh)
     bad = (np.abs(img_g[..., :3] - img_o[..., :3]) > 2e-5 * np.maximum(1.0, np.abs(img_o[..., :3]))).any(axis=-1)
+    if not wide and sg.rays == so.rays and not bad.any():
+        # the reference's visiting order: the traversal counters are the oracle's (a tie that falls the other way moves them
+        # by a ray's worth)
+        _, sc_ = g.render_counted(fw, fh)
+        for name in ("nodes_visited", "triangles_tested", "instances_entered", "instances_tested"):
+            a_, b_ = int(getattr(sc_, name)), int(getattr(so, name))
+            if abs(a_ - b_) > max(2000, 1e-4 * b_):
+                fails.append(f"counter {name}: {a_} vs {b_}")
     what = f"frame program={program} {fw}x{fh} spp={spp} b={bounces} r={newrays} single={single} wide={wide} {opts}"
     # a tie resolved the other way changes one path's subtree: a handful of rays, one pixel
     few_rays, few_pixels = max(8, 2e-5 * so.rays), max(1, 3e-4 * fw * fh)
