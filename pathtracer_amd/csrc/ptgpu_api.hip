@@ -436,7 +436,10 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     const uint64_t per_slot = static_cast<uint64_t>(tiles.count) * 64ull;
     uint32_t slots_per_batch = 0;
     uint64_t K;
-    if (per_slot <= c->chunk && n_slots) {
+#ifndef PT_SAMPLE_MAJOR
+#define PT_SAMPLE_MAJOR 0  // 1: developer builds, the linear sample-major order for every frame (measured slower, see EXPERIMENTS)
+#endif
+    if (per_slot <= c->chunk && n_slots && !PT_SAMPLE_MAJOR) {
         const uint64_t fit = c->chunk / per_slot;
         const uint64_t n_batches = (n_slots + fit - 1) / fit;
         slots_per_batch = static_cast<uint32_t>((n_slots + n_batches - 1) / n_batches);
