@@ -1688,9 +1688,19 @@ __device__ __forceinline__ void append_rays(const bool (&has)[NSLOT], const floa
 
 __device__ __forceinline__ void add_radiance(FrameDev fb, uint32_t pid, f3 c) {
     if (c.x != 0.0f || c.y != 0.0f || c.z != 0.0f) {
+        // the bucket: binades 2^-40 .. 2^8 of the largest component in eight steps of six (smaller and larger ones, and
+        // contributions that are not numbers, go to the ends)
+        if constexpr (kFrameBuckets == 8) {
+        // (magnitudes compare like their bit patterns)
+        const uint32_t mx = __float_as_uint(c.x) & 0x7fffffffu, my = __float_as_uint(c.y) & 0x7fffffffu, mz = __float_as_uint(c.z) & 0x7fffffffu;
+        const uint32_t m = mx > my ? (mx > mz ? mx : mz) : (my > mz ? my : mz);
+        int e = static_cast<int>(m >> 23) - (127 - 40);
+        e = e < 0 ? 0 : (e > 47 ? 47 : e);
+        pid += ((static_cast<uint32_t>(e) * 43u) >> 8) * 3u * fb.stride;  // e / 6 for 0 <= e < 48; an index below 2^32
+        }
         atomicAdd(fb.sum + pid, c.x);
-        atomicAdd(fb.sum + fb.stride + pid, c.y);
-        atomicAdd(fb.sum + 2u * fb.stride + pid, c.z);
+        atomicAdd(fb.sum + pid + fb.stride, c.y);
+        atomicAdd(fb.sum + pid + 2u * fb.stride, c.z);
     }
 }
 
@@ -1873,9 +1883,9 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
         const bool marked = (__float_as_uint(rp.x) >> 31) != 0u;
         payload = f3{fabsf(rp.x), rp.y, rp.z};
         const f3 dir = ld3(rd);
-        f3 radiance = mk3(0.0f);
+        // (radiance is added where it is known, not after the branches have joined: three registers less across the lobes' set-up)
         if (!(h1 & 0x80000000u)) {
-            radiance = payload * sample_environment(sc, dir);
+            add_radiance(fb, pid, payload * sample_environment(sc, dir));
         } else {
             const bool backface = (h1 & 0x40000000u) != 0;
             const float4 h0 = hits.h0[i];  // written for hits only
@@ -1908,7 +1918,7 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                     atten = f3{sel_min(pt_exp(e.x), 1.0f), sel_min(pt_exp(e.y), 1.0f), sel_min(pt_exp(e.z), 1.0f)};
                 }
                 const f3 emissive = sample_emissive(sc, mat, sp.p.u, sp.p.v);
-                radiance = payload * emissive * atten * alpha;
+                add_radiance(fb, pid, payload * emissive * atten * alpha);
                 if (depth != 0) {
                     const f3 v = -dir;
                     const float4 nm = sample_normals(sc, mat, sp.p.u, sp.p.v);
@@ -1945,7 +1955,6 @@ __global__ PT_SHADE_BOUNDS void shade_pbr_kernel(SceneDev sc, RayQueue rays, uin
                 }
             }
         }
-        add_radiance(fb, pid, radiance);
     }
 
     const uint32_t lane_id = threadIdx.x & 63u;
@@ -2076,7 +2085,14 @@ __global__ __launch_bounds__(kBlock) void resolve_kernel(FrameDev fb, CameraDev 
     const uint32_t x = i % cam.width, y = i / cam.width;
     const uint32_t tile = (y / kTile) * cam.tiles_x + (x / kTile);
     const uint32_t pid = tile * 64u + (y % kTile) * 8u + (x % kTile);
-    out[i] = make_float4(fb.sum[pid] / divisor, fb.sum[fb.stride + pid] / divisor, fb.sum[2u * fb.stride + pid] / divisor, alpha);
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    for (uint32_t k = 0; k < kFrameBuckets; ++k) {  // smallest magnitudes first
+        const float* sum = fb.sum + static_cast<size_t>(k) * 3u * fb.stride;
+        r += sum[pid];
+        g += sum[fb.stride + pid];
+        b += sum[2u * fb.stride + pid];
+    }
+    out[i] = make_float4(r / divisor, g / divisor, b / divisor, alpha);
 }
 __global__ __launch_bounds__(kBlock) void divide_rgba_kernel(float4* __restrict__ p, uint64_t n, float divisor) {
     const uint64_t i = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;

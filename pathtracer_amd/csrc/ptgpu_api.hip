@@ -454,10 +454,10 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     int rc = ensure_work_memory(c, fanout, bounces, K, L_want);
     if (rc) return rc;
     const uint64_t L = c->launch_cap;
-    PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4));
+    PT_HIP(c, c->fb.ensure(static_cast<size_t>(g.fb_stride) * 3 * 4 * ptd::kFrameBuckets));
     ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride, c->counter.as<uint32_t>() + 2};  // (word 0 of that buffer is the queue counter)
     PT_HIP(c, hipMemsetAsync(fb.abandoned, 0, 4, st));
-    ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3);  // framebuffer.clear, renderer.cc:85
+    ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3 * ptd::kFrameBuckets);  // framebuffer.clear, renderer.cc:85
     const std::vector<float> sub = subsample_table(spp);
     PT_HIP(c, c->subs.ensure(sub.size() * 4));
     PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
