@@ -376,12 +376,15 @@ bool collapse_to_wide(const std::vector<ptd::DevNode>& nodes, const std::vector<
                     step = std::max(std::nextafter(step, std::numeric_limits<float>::max()), step * (1.0f + grow));
                 nd.origin[a] = lo;
                 nd.scale[a] = step;
+                // (clamped before the conversion: with coordinates that validation refuses the quotient can be infinite or
+                // not a number, which no int holds)
+                const auto to_step = [](float x) { return !(x > 0.0f) ? 0 : (x >= 255.0f ? 255 : static_cast<int>(x)); };
                 for (int k = 0; k < n_ch; ++k) {
                     int ql = 0, qh = 0;
                     if (step > 0.0f) {
-                        ql = std::clamp(static_cast<int>(std::floor((ch[k].lo[a] - lo) / step)), 0, 255);
+                        ql = to_step(std::floor((ch[k].lo[a] - lo) / step));
                         while (ql > 0 && lo + step * static_cast<float>(ql) > ch[k].lo[a]) --ql;
-                        qh = std::clamp(static_cast<int>(std::ceil((ch[k].hi[a] - lo) / step)), 0, 255);
+                        qh = to_step(std::ceil((ch[k].hi[a] - lo) / step));
                         while (qh < 255 && lo + step * static_cast<float>(qh) < ch[k].hi[a]) ++qh;
                     }
                     nd.qlo[a] |= static_cast<uint32_t>(ql) << (8 * k);

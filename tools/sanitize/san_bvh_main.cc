@@ -5,8 +5,8 @@
 // exactly one leaf, leaf sizes, boxes nested).  Then the whole scene build with four-wide nodes — the optimal and the greedy
 // collapse, the 8-bit quantisation, the numbering of the most visited nodes, the tree over the instance bounds — checked for:
 // every triangle in one leaf of the wide tree, every child's decoded box containing its triangles after rounding, unused
-// slots inverted and pointing at the dummy leaf, the instance tree holding every instance once; and models with
-// not-a-number or overflowing coordinates refused instead of walked.  No GPU call is made.  Prints a line per case.
+// slots inverted and pointing at the dummy leaf, the instance tree holding every instance once; an object scaled to nothing
+// left out of the instances; and models with not-a-number or overflowing coordinates refused instead of walked.  No GPU call is made.  Prints a line per case.
 #include <cstdint>
 #include <cstdio>
 #include <cmath>
@@ -401,6 +401,25 @@ int main() {
         check(!pth::validate_model(tm.model, &err), "a NaN matrix entry is refused");
         tm.objects[0].model_matrix[13] = 0.0f;
         check(pth::validate_model(tm.model, &err), "the repaired model validates");
+        // an object whose model matrix cannot be inverted arrives with a normal matrix that is not finite: the model is
+        // accepted, the object is left out of the instances and the rest of the scene is built as usual
+        for (float bad : {std::numeric_limits<float>::quiet_NaN(), std::numeric_limits<float>::infinity()})
+            for (uint32_t victim : {0u, 3u, 6u}) {
+                TestModel hm;
+                make_model(hm, {40u, 90u, 20u, 64u, 150u}, 7, 0.0f);
+                hm.objects[victim].model_matrix[0] = 0.0f;
+                for (int k : {0, 5, 10}) hm.objects[victim].normal_matrix[k] = bad;
+                check(pth::validate_model(hm.model, &err), "an object scaled to nothing is accepted");
+                pth::BuildOptions bo;
+                bo.want_wide = true;
+                pth::BuiltScene built;
+                int code = 0;
+                check(pth::build_scene(hm.model, bo, built, &err, &code), "the scene around it builds");
+                check(built.instances.size() == 6u, "it is left out of the instances");
+                for (const auto& in : built.instances) check(in.object_index != victim && in.object_index < 7u, "the others keep their object numbers");
+                wide_nodes += check_wide(built);
+                check_instance_tree(built);
+            }
         // the builders themselves on what validation would have refused: they must terminate inside their arrays and either
         // produce a structurally sound result or say why not
         for (float bad : {std::numeric_limits<float>::quiet_NaN(), 1.0e20f, -1.0e30f, std::numeric_limits<float>::infinity()}) {
