@@ -110,6 +110,9 @@ struct TraceCounters {   // filled by the counting variant of extend
 struct TileSubset {
     uint32_t begin, step, count;
 };
+// True when launch_generate writes ray i of a batch to slot i and the count it reports is the batch size (the frame is a
+// whole number of tiles, so every index has a pixel).
+bool generate_is_dense(const CameraDev& cam);
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
                      uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count);

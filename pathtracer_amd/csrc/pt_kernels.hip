@@ -2161,11 +2161,12 @@ hipError_t take_launch_error(const char** kernel) {
     return e;
 }
 
+bool generate_is_dense(const CameraDev& cam) { return cam.width % kTile == 0 && cam.height % kTile == 0; }
 void launch_generate(hipStream_t st, const CameraDev& cam, const float2* subsamples, uint32_t sample_begin,
                      uint32_t sample_step, uint32_t max_bounces, uint32_t seed, uint64_t first, uint32_t n,
                      uint32_t slots_in_batch, TileSubset tiles, RayQueue out, uint32_t* out_count) {
     if (!n) return;
-    if (cam.width % kTile == 0 && cam.height % kTile == 0)
+    if (generate_is_dense(cam))
         PT_LAUNCH(generate_kernel<true>, dim3(blocks_for(n)), dim3(kBlock), 0, st, cam, subsamples, sample_begin,
                            sample_step, max_bounces, seed, first, n, slots_in_batch, tiles.begin, tiles.step, tiles.count, out, out_count);
     else

@@ -202,7 +202,9 @@ struct ptgpu_ctx {
     bool persistent = true;        // extend kernel form (PTGPU_EXTEND=simple selects one ray per lane)
     uint32_t persist_blocks = 0;   // resident workgroups of the persistent extend kernel
     uint32_t* host_counter = nullptr;  // pinned
-    hipEvent_t ev[7] = {};
+    hipEvent_t ev[9] = {};         // (7, 8: around the camera-ray kernel of a batch whose ray count needs no readback)
+    std::vector<float> subs_host;  // the subsample table on the device is that of subs_spp samples per pixel (0: none yet)
+    uint32_t subs_spp = 0;
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -399,6 +401,19 @@ void run_extend(ptgpu_ctx* c, hipStream_t st, const ptd::RayQueue& rq, uint32_t 
         ptd::launch_extend(st, c->scene, rq, n, hits, c->spill.as<uint32_t>(), spill_depth, c->launch_cap, tc);
 }
 
+// The subsample positions of `spp` samples per pixel in c->subs; computed and copied only when spp changes (a preview loop
+// renders the same settings frame after frame, and the copy from pageable memory costs more than its 8 bytes per sample).
+int upload_subsamples(ptgpu_ctx* c, uint32_t spp, hipStream_t st) {
+    if (c->subs_spp == spp && c->subs.p) return PTGPU_OK;
+    c->subs_spp = 0;
+    c->subs_host = subsample_table(spp);  // (kept in the context: the copy may still be reading it when this returns)
+    PT_HIP(c, c->subs.ensure(c->subs_host.size() * 4));
+    PT_HIP(c, hipMemcpyAsync(c->subs.p, c->subs_host.data(), c->subs_host.size() * 4, hipMemcpyHostToDevice, st));
+    PT_HIP(c, hipStreamSynchronize(st));  // later frames may run on another stream
+    c->subs_spp = spp;
+    return PTGPU_OK;
+}
+
 struct RenderOut {
     float* d_rgba;    // device RGBA row-major destination (may be null)
     bool mean;        // divide by the number of samples rendered
@@ -458,9 +473,7 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     ptd::FrameDev fb{c->fb.as<float>(), g.fb_stride, c->counter.as<uint32_t>() + 2};  // (word 0 of that buffer is the queue counter)
     PT_HIP(c, hipMemsetAsync(fb.abandoned, 0, 4, st));
     ptd::launch_clear(st, fb.sum, static_cast<uint64_t>(g.fb_stride) * 3 * ptd::kFrameBuckets);  // framebuffer.clear, renderer.cc:85
-    const std::vector<float> sub = subsample_table(spp);
-    PT_HIP(c, c->subs.ensure(sub.size() * 4));
-    PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
+    if (const int rc_subs = upload_subsamples(c, spp, st)) return rc_subs;
     ptd::TraceCounters* d_tc = counted ? c->trace_counters.as<ptd::TraceCounters>() : nullptr;
     if (counted) PT_HIP(c, hipMemsetAsync(d_tc, 0, sizeof(ptd::TraceCounters), st));
 
@@ -501,14 +514,22 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     // end of a batch are slivers of a few thousand rays), and every launch saved is a tail saved.
     const uint64_t carry_below = (L > K) ? L - K + 1 : K / 32;
     int gen_pool = 0;  // pool that receives the next batch's camera rays (the one holding carried rays, if any)
+    bool generate_untimed = false;  // events 7 / 8 hold a camera-ray kernel's time that has not been read yet
+    // A frame that is ONE launch with nothing to read back (a preview frame: one batch, no spawned rays) is not waited for
+    // launch by launch either: its times are read after the frame's last kernel.
+    const bool one_launch = !fanout && total <= K && total <= L;
+    bool launch_untimed = false;
     c->pools[0].top = c->pools[1].top = 0;
     for (uint64_t first = 0; first < total; first += K) {
         const uint32_t n_gen = static_cast<uint32_t>(std::min<uint64_t>(K, total - first));
         const bool last_batch = first + K >= total;
         Pool& gp = c->pools[gen_pool];
         if (gp.top + n_gen > gp.cap) return c->fail(PTGPU_E_NOMEM, "ray pool too small for a batch of camera rays");
+        // A frame of whole tiles has a ray for every index of the batch: its count is known here, and the host does not
+        // wait for the kernel (the kernel's time is read at the next point where it waits anyway).
+        const bool count_known = ptd::generate_is_dense(g.cam);
         PT_HIP(c, hipMemsetAsync(d_count, 0, 4, st));
-        PT_HIP(c, hipEventRecord(c->ev[0], st));
+        PT_HIP(c, hipEventRecord(c->ev[count_known ? 7 : 0], st));
         if (slots_per_batch) {
             const uint32_t slot0 = static_cast<uint32_t>(first / per_slot);
             ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, slot0, n_gen,
@@ -517,12 +538,17 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             ptd::launch_generate(st, g.cam, c->subs.as<float2>(), begin, step, bounces, s.seed, first, n_gen, 0, tiles, gp.at(gp.top),
                                  d_count);
         }
-        PT_HIP(c, hipEventRecord(c->ev[1], st));
-        PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
-        PT_SYNC(c, st);
-        PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
-        out.generate_ms += ms;
-        const uint32_t n_cam = *c->host_counter;
+        PT_HIP(c, hipEventRecord(c->ev[count_known ? 8 : 1], st));
+        uint32_t n_cam = n_gen;
+        if (count_known) {
+            generate_untimed = true;
+        } else {
+            PT_HIP(c, hipMemcpyAsync(c->host_counter, d_count, 4, hipMemcpyDeviceToHost, st));
+            PT_SYNC(c, st);
+            PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            out.generate_ms += ms;
+            n_cam = *c->host_counter;
+        }
         out.camera_samples += n_cam;
         gp.top += n_cam;
         if (!gp.top) continue;
@@ -589,7 +615,20 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
             const bool through_streams = ptd::shade_reserves_through_streams(program, n, use_streams ? &streams : nullptr);
             if (through_streams)
                 PT_HIP(c, hipMemcpyAsync(c->host_counter + 1, streams.cursors + ptd::kShadeStreamWords - 1, 4, hipMemcpyDeviceToHost, st));
+            if (one_launch) {
+                launch_untimed = true;
+                out.rays += n;
+                ++out.extend_launches;
+                ++out.shade_launches;
+                in.top = offset;
+                continue;
+            }
             PT_SYNC(c, st);
+            if (generate_untimed) {
+                PT_HIP(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[8]));
+                out.generate_ms += ms;
+                generate_untimed = false;
+            }
             if (through_streams && c->host_counter[1] != 0) {
                 // the streams ended further apart than the staging queue holds (a launch whose workgroups' yields follow
                 // their position modulo the number of streams): slower, piece by piece
@@ -618,6 +657,20 @@ int render_core(ptgpu_ctx* c, int width, int height, hipStream_t st, bool counte
     PT_HIP(c, hipEventRecord(c->ev[5], st));
     PT_HIP(c, hipMemcpyAsync(c->host_counter + 2, fb.abandoned, 4, hipMemcpyDeviceToHost, st));
     PT_SYNC(c, st);
+    if (generate_untimed) {
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev[7], c->ev[8]));
+        out.generate_ms += ms;
+    }
+    if (launch_untimed) {
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+        out.extend_ms += ms;
+        if (c->persistent) {
+            PT_HIP(c, hipEventElapsedTime(&ms, c->ev[6], c->ev[1]));
+            out.traverse_ms += ms;
+        }
+        PT_HIP(c, hipEventElapsedTime(&ms, c->ev[2], c->ev[3]));
+        out.shade_ms += ms;
+    }
     PT_HIP(c, hipEventElapsedTime(&ms, c->ev[4], c->ev[5]));
     out.total_ms = ms;
     out.rays_abandoned = c->host_counter[2];
@@ -1028,9 +1081,7 @@ int ptgpu_render_hits(ptgpu_ctx* c, int width, int height, uint32_t sample, ptgp
     int rc = ensure_work_memory(c, 0, 0, K, K);
     if (rc) return rc;
     hipStream_t st = c->stream;
-    const std::vector<float> sub = subsample_table(spp);
-    PT_HIP(c, c->subs.ensure(sub.size() * 4));
-    PT_HIP(c, hipMemcpyAsync(c->subs.p, sub.data(), sub.size() * 4, hipMemcpyHostToDevice, st));
+    if (const int rc_subs = upload_subsamples(c, spp, st)) return rc_subs;
     ptd::HitQueue hits{c->hit0.as<float4>(), c->hit1.as<uint32_t>()};
     std::vector<float4> h0, ro;
     std::vector<uint32_t> h1;
