@@ -119,3 +119,35 @@ def test_an_object_scaled_to_nothing_is_left_out():
             assert s.rays == so.rays
             assert np.abs(img[..., :3] - img_o[..., :3]).max() <= 2e-5 * max(1.0, np.abs(img_o[..., :3]).max())
             assert ((g.get_scene_bound()[0] == o.get_scene_bound()[0]).all() and (g.get_scene_bound()[1] == o.get_scene_bound()[1]).all())
+
+
+def test_a_preview_loop_on_one_context():
+    """One context rendering frame after frame, as the viewer does (viewer.cc:54-105): the sample count and the frame size
+    change between frames, and a hit dump runs in between.  The library keeps the subsample table of the last sample count
+    on the device and does not wait for the camera-ray kernel of a frame of whole tiles, so every frame is checked against
+    the oracle's: the counts of camera samples and rays equal, the picture within the accumulation tolerance.  A table left
+    over from another sample count moves every sample inside its pixel, far beyond that."""
+    from pathtracer_amd.renderer import Perspective
+    model, env = scenes.tiny_scene(), scenes.synthetic_env()
+    cam = model.cameras[0]
+    # (samples per pixel, width, height): whole tiles and ragged frames
+    frames = [(4, 64, 40), (2, 64, 40), (2, 33, 17), (3, 64, 40), (1, 35, 24), (4, 64, 40)]
+    for program in (0, 1):  # one launch per frame / spawned rays and several launches (the program is fixed when the scene is loaded)
+        gpu = None
+        for spp, w, h in frames:
+            st = H.settings(program=program, spp=spp, bounces=3, newrays=4)
+            if gpu is None:
+                gpu = H.make_gpu(model, env, st, w, h)
+            gpu.set_render_settings(st)
+            gpu.update_camera_transform_state(cam.position, cam.direction, cam.up, Perspective(cam.yfov, cam.znear, w / h, cam.zfar))
+            img, stats = H.gpu_render(gpu, w, h)
+            o = H.make_oracle(model, env, st, w, h)
+            ref, ref_stats = o.render_frame(w, h)
+            assert stats.camera_samples == w * h * spp and stats.rays == ref_stats.rays, (program, spp, w, h)
+            assert stats.generate_ms > 0.0 and stats.extend_ms > 0.0 and stats.shade_ms > 0.0
+            assert stats.total_ms >= stats.extend_ms + stats.shade_ms
+            bad = np.abs(img[..., :3] - ref[..., :3]) > 2e-5 * np.maximum(1.0, np.abs(ref[..., :3]))
+            assert not bad.any(), (program, spp, w, h, int(bad.sum()))
+            # a hit dump of the last sample between two frames reads the same table
+            exact, _ = H.hits_equal(o.render_hits(w, h, spp - 1), gpu.render_hits(w, h, spp - 1))
+            assert exact.all(), (program, spp, w, h)
